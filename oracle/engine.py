@@ -1,0 +1,121 @@
+"""Oracle compute engine: one nonlinear solve = the reference's ``self.solver.solve()``
+(/root/reference/thermalporous/thermalmodel.py:165): SNES newtonls with the `basic` line search
+Firedrake selects by default, right-preconditioned FGMRES, composite CPR/CPTR preconditioner.
+Test infrastructure only (see oracle/__init__.py).
+
+Same interface as thermalporous_amd.engine.HipEngine so that the host time loop
+(thermalporous_amd/thermalmodel.py) can be exercised on CPU in tests by injection.
+"""
+import numpy as np
+
+from .tpfa import Problem
+from . import linalg as la
+
+# SNES / KSP reason codes (PETSc numbering)
+SNES_CONVERGED_FNORM_ABS = 2
+SNES_CONVERGED_FNORM_RELATIVE = 3
+SNES_CONVERGED_SNORM_RELATIVE = 4
+SNES_DIVERGED_LINEAR_SOLVE = -3
+SNES_DIVERGED_FNORM_NAN = -4
+SNES_DIVERGED_MAX_IT = -5
+
+DEFAULT_OPTS = dict(
+    pc="cpr", decoup="No",
+    ksp_rtol=1e-7, ksp_atol=1e-50, ksp_max_it=200, ksp_restart=200,
+    snes_rtol=1e-8, snes_atol=1e-50, snes_stol=1e-8, snes_max_it=15,
+    amg_omega=0.8, amg_min_cells=64, amg_nu=2,
+    ilu_tile=(1 << 30, 8, 8),
+)
+
+
+class OracleEngine:
+    def __init__(self, spec, opts=None):
+        self.spec = spec
+        self.opts = dict(DEFAULT_OPTS)
+        self.opts.update(opts or {})
+        self.prob = Problem(spec)
+        self.b = self.prob.b
+        self.u = None
+        self.pc = la.TwoStagePC(self.prob, self.opts)
+        self.last = {}
+
+    # state ------------------------------------------------------------------------------
+    def set_state(self, u):
+        self.u = self.prob.as_fields(np.array(u, dtype=float)).copy()
+
+    def get_state(self):
+        return self.u.copy()
+
+    def set_old(self, u):
+        self.prob.set_old(np.array(u, dtype=float))
+
+    def set_dt(self, dt):
+        self.prob.set_dt(dt)
+
+    # pieces, exposed for parity tests ------------------------------------------------------
+    def residual(self, u=None):
+        return self.prob.residual(self.u if u is None else u)
+
+    def jacobian(self, u=None, want_schur=False):
+        return self.prob.jacobian(self.u if u is None else u, want_schur=want_schur)
+
+    def well_rates(self, u=None):
+        u = self.prob.as_fields(self.u if u is None else u)
+        if self.prob.src is None:
+            return {}
+        c = self.prob.src["cell"]
+        p, T, S = self.prob.split(u)
+        args = [x.reshape(-1)[c] if x is not None else None for x in (p, T, S)]
+        _, rates = self.prob.source_terms(*args, return_rates=True)
+        return rates
+
+    # the hot path --------------------------------------------------------------------------
+    def linear_solve(self, J, Sm, F):
+        o = self.opts
+        self.pc.setup(J, Sm)
+        return la.fgmres(lambda x: la.spmv_block(J, x), self.pc.apply, F, rtol=o["ksp_rtol"], atol=o["ksp_atol"],
+                         restart=o["ksp_restart"], maxit=o["ksp_max_it"])
+
+    def newton_solve(self):
+        o = self.opts
+        u = self.u
+        want_schur = o["pc"] == "cptr"
+        F = self.prob.residual(u)
+        fnorm = float(np.linalg.norm(F))
+        fnorm0 = fnorm
+        nits, lits = 0, 0
+        reason = 0
+        hist = [fnorm]
+        if not np.isfinite(fnorm):
+            reason = SNES_DIVERGED_FNORM_NAN
+        elif fnorm < o["snes_atol"]:
+            reason = SNES_CONVERGED_FNORM_ABS
+        while reason == 0:
+            if nits >= o["snes_max_it"]:
+                reason = SNES_DIVERGED_MAX_IT
+                break
+            out = self.prob.jacobian(u, want_schur=want_schur)
+            J, Sm = out if want_schur else (out, None)
+            dx, kits, kreason, _ = self.linear_solve(J, Sm, F)
+            lits += kits
+            if kreason < 0:
+                reason = SNES_DIVERGED_LINEAR_SOLVE
+                break
+            u = u - dx                                    # basic line search, lambda = 1
+            F = self.prob.residual(u)
+            fnorm = float(np.linalg.norm(F))
+            nits += 1
+            hist.append(fnorm)
+            snorm = float(np.linalg.norm(dx))
+            xnorm = float(np.linalg.norm(u))
+            if not np.isfinite(fnorm):
+                reason = SNES_DIVERGED_FNORM_NAN
+            elif fnorm < o["snes_atol"]:
+                reason = SNES_CONVERGED_FNORM_ABS
+            elif fnorm <= o["snes_rtol"] * fnorm0:
+                reason = SNES_CONVERGED_FNORM_RELATIVE
+            elif snorm < o["snes_stol"] * xnorm:
+                reason = SNES_CONVERGED_SNORM_RELATIVE
+        self.u = u
+        self.last = dict(nits=nits, lits=lits, reason=reason, fnorm=fnorm, fnorm0=fnorm0, history=hist)
+        return self.last

@@ -1,0 +1,468 @@
+"""Linear algebra of the hot path on the structured 7-point stencil (oracle; test infrastructure).
+
+What the reference delegates to PETSc/hypre, restated so that the HIP
+kernels have a CPU checker computing the SAME algorithm:
+  * MatMult on the 7-point block stencil                      (PETSc MatMult AIJ)
+  * stage 2: block-Jacobi over tiles + block-ILU(0) per tile   (sub_1_* bjacobi/ilu levels 0,
+    singlephase.py:348-349, twophase.py:547-548; ``-sub_1_pc_bjacobi_blocks`` tests/test_homo_wells.py:112,125)
+  * stage 1 operators: Quasi-/True-IMPES decoupling            (preconditioners.py:684-711,785-808,1445-1543)
+  * pressure / temperature AMG V-cycle                         (v_cycle dicts singlephase.py:303-307)
+  * fieldsplit Schur FULL apply for pc_cptr                    (twophase.py:536-545)
+  * FGMRES, right preconditioned, classical Gram-Schmidt       (twophase.py:426-432)
+hypre's BoomerAMG and PETSc's point-ILU on DMPlex numbering are not reproducible; the AMG here
+is a structured semicoarsening AMG (SemiAMG below) and the ILU is the exact block ILU(0) of each tile in
+natural order.  Iteration counts are therefore this build's own ("parity unpinned").
+
+Stencil slots: 0 diag, 1 (-a0), 2 (+a0), 3 (-a1), 4 (+a1), 5 (-a2), 6 (+a2); arrays (.., n2, n1, n0).
+"""
+import numpy as np
+
+from .tpfa import _lo, _hi
+
+
+# ------------------------------------------------------------------ stencil mat-vec
+def spmv_scalar(A, x):
+    y = A[0] * x
+    for a in range(3):
+        if x.shape[2 - a] == 1:
+            continue
+        lo, hi = _lo(a), _hi(a)
+        y[lo] += A[2 + 2 * a][lo] * x[hi]
+        y[hi] += A[1 + 2 * a][hi] * x[lo]
+    return y
+
+
+def spmv_block(J, x):
+    b = J.shape[1]
+    y = np.zeros_like(x)
+    for r in range(b):
+        for c in range(b):
+            y[r] += spmv_scalar(J[:, r, c], x[c])
+    return y
+
+
+def to_csr(J):
+    """Assemble the block stencil into scipy CSR (cell-interleaved ordering) for direct-solve checks."""
+    import scipy.sparse as sp
+    b = J.shape[1]
+    shape = J.shape[3:]
+    n = int(np.prod(shape))
+    n2, n1, n0 = shape
+    idx = np.arange(n).reshape(shape)
+    rows, cols, vals = [], [], []
+    strides = (1, n0, n0 * n1)
+    for s in range(7):
+        if s == 0:
+            sel, off = (slice(None),) * 3, 0
+        else:
+            a = (s - 1) // 2
+            if shape[2 - a] == 1:
+                continue
+            sel = _hi(a) if s % 2 == 1 else _lo(a)
+            off = -strides[a] if s % 2 == 1 else strides[a]
+        for r in range(b):
+            for c in range(b):
+                rr = idx[sel].reshape(-1)
+                rows.append(rr * b + r)
+                cols.append((rr + off) * b + c)
+                vals.append(J[s, r, c][sel].reshape(-1))
+    return sp.csr_matrix((np.concatenate(vals), (np.concatenate(rows), np.concatenate(cols))), shape=(n * b, n * b))
+
+
+# ------------------------------------------------------------------ stage 2: tiled block ILU(0)
+class TiledILU0:
+    """Block-Jacobi over box tiles, exact block-ILU(0) in natural order inside each tile.
+
+    On a 7-point stencil ILU(0) creates no off-diagonal updates (the lower neighbours of a cell
+    are not adjacent to each other), so the factor is  M = (D~ + L_A) D~^-1 (D~ + U_A)  with
+    D~_c = A_cc - sum_{m lower, same tile} A_cm D~_m^-1 A_mc.  Couplings that leave the tile are
+    dropped (= PETSc bjacobi with one block per tile)."""
+
+    def __init__(self, shape, tile):
+        n2, n1, n0 = shape
+        self.shape = shape
+        t0, t1, t2 = (max(1, min(int(t), n)) for t, n in zip(tile, (n0, n1, n2)))
+        self.tile = (t0, t1, t2)
+        i2, i1, i0 = np.meshgrid(np.arange(n2), np.arange(n1), np.arange(n0), indexing="ij")
+        self.l = [i0 % t0, i1 % t1, i2 % t2]
+        self.tdim = [np.minimum(t, n - (i // t) * t) for t, n, i in zip((t0, t1, t2), (n0, n1, n2), (i0, i1, i2))]
+        self.level = (self.l[0] + self.l[1] + self.l[2]).reshape(-1)
+        self.nlev = int(self.level.max()) + 1
+        self.strides = (1, n0, n0 * n1)
+        order = np.argsort(self.level, kind="stable")
+        bounds = np.searchsorted(self.level[order], np.arange(self.nlev + 1))
+        self.cells_at = [order[bounds[s]:bounds[s + 1]] for s in range(self.nlev)]
+        lf = [x.reshape(-1) for x in self.l]
+        td = [x.reshape(-1) for x in self.tdim]
+        self.has_lo = [lf[a] > 0 for a in range(3)]
+        self.has_hi = [lf[a] < td[a] - 1 for a in range(3)]
+        self.Dinv = None
+
+    def factor(self, J):
+        b = J.shape[1]
+        n = int(np.prod(self.shape))
+        Jf = J.reshape(7, b, b, n)
+        self.J = Jf
+        Dinv = np.zeros((b, b, n))
+        for s in range(self.nlev):
+            c = self.cells_at[s]
+            D = Jf[0][:, :, c].copy()
+            for a in range(3):
+                m = self.has_lo[a][c]
+                cc = c[m]
+                if len(cc) == 0:
+                    continue
+                nb = cc - self.strides[a]
+                # A_cm D~_m^-1 A_mc : A_cm = slot(-a) at c ; A_mc = slot(+a) at m
+                t = np.einsum("ijn,jkn,kln->iln", Jf[1 + 2 * a][:, :, cc], Dinv[:, :, nb], Jf[2 + 2 * a][:, :, nb])
+                D[:, :, m] -= t
+            Dinv[:, :, c] = np.linalg.inv(D.transpose(2, 0, 1)).transpose(1, 2, 0)
+        self.Dinv = Dinv
+        return self
+
+    def solve(self, r):
+        b = self.J.shape[1]
+        n = int(np.prod(self.shape))
+        Jf, Dinv = self.J, self.Dinv
+        rf = r.reshape(b, n)
+        y = np.zeros((b, n))
+        for s in range(self.nlev):                     # (I + L_A D~^-1) y = r
+            c = self.cells_at[s]
+            t = rf[:, c].copy()
+            for a in range(3):
+                m = self.has_lo[a][c]
+                cc = c[m]
+                if len(cc) == 0:
+                    continue
+                nb = cc - self.strides[a]
+                t[:, m] -= np.einsum("ijn,jkn,kn->in", Jf[1 + 2 * a][:, :, cc], Dinv[:, :, nb], y[:, nb])
+            y[:, c] = t
+        x = np.zeros((b, n))
+        for s in range(self.nlev - 1, -1, -1):         # (D~ + U_A) x = y
+            c = self.cells_at[s]
+            t = y[:, c].copy()
+            for a in range(3):
+                m = self.has_hi[a][c]
+                cc = c[m]
+                if len(cc) == 0:
+                    continue
+                nb = cc + self.strides[a]
+                t[:, m] -= np.einsum("ijn,jn->in", Jf[2 + 2 * a][:, :, cc], x[:, nb])
+            x[:, c] = np.einsum("ijn,jn->in", Dinv[:, :, c], t)
+        return x.reshape(r.shape)
+
+
+# ------------------------------------------------------------------ semicoarsening AMG (7-point on every level)
+def _axsl(ax, sl, ndim=3):
+    s = [slice(None)] * ndim
+    s[ax] = sl
+    return tuple(s)
+
+
+class SemiAMG:
+    """Structured semicoarsening AMG in the spirit of hypre's PFMG with non-Galerkin 7-point
+    coarse operators (the reference's v_cycle is hypre BoomerAMG, singlephase.py:303-307, which
+    cannot be reproduced; this is the build's own pressure AMG).
+
+    Level l -> l+1 along internal axis a: C points = even indices along a.  An F point g between
+    C points interpolates with operator weights  w-(g) = -a_-(g)/c(g), w+(g) = -a_+(g)/c(g),
+    c(g) = a_0(g) + sum of its cross-axis off-diagonals (stencil collapsed onto the a-line).
+    R = P^T.  Coarse operator at C point f (neighbours g- = f-a, g+ = f+a):
+        A_c[-a] = a_-(f) w-(g-)          A_c[+a] = a_+(f) w+(g+)
+        A_c[d]  = a_d(f) + w+(g-) a_d(g-) + w-(g+) a_d(g+)          (cross slots d)
+        A_c[0]  = -sum(off-diagonals of the coarse row) + rho(f) + w+(g-) rho(g-) + w-(g+) rho(g+)
+    with rho = fine row sums (the accumulation part), so M-matrix structure and the zero-order
+    term are kept and every level stays a 7-point stencil.  V(nu,nu) cycle, damped Jacobi.
+    """
+
+    def __init__(self, n, strength, omega=0.8, min_cells=64, nu=1, max_levels=40):
+        self.n = tuple(n)
+        self.omega, self.nu = omega, nu
+        self.sched = self._schedule(n, strength, min_cells, max_levels)
+
+    @staticmethod
+    def _schedule(n, strength, min_cells, max_levels):
+        n = list(n)
+        s = [float(v) if n[a] > 1 else -1.0 for a, v in enumerate(strength)]
+        sched = []
+        while n[0] * n[1] * n[2] > min_cells and len(sched) < max_levels:
+            cand = [a for a in range(3) if n[a] > 1]
+            if not cand:
+                break
+            a = max(cand, key=lambda q: (s[q], -q))
+            sched.append(a)
+            n[a] = (n[a] + 1) // 2
+            for q in range(3):
+                s[q] = s[q] * 0.5 if q == a else s[q] * 2.0
+        return sched
+
+    @staticmethod
+    def weights(A, a):
+        """Interpolation weights (w-, w+) at every cell (only odd cells along a are used)."""
+        cross = [s for s in range(1, 7) if (s - 1) // 2 != a]
+        c = A[0] + sum(A[s] for s in cross)
+        return -A[1 + 2 * a] / c, -A[2 + 2 * a] / c
+
+    @staticmethod
+    def coarsen(A, a):
+        ax = 2 - a
+        n = A.shape[1 + ax]
+        nc = (n + 1) // 2
+        wm, wp = SemiAMG.weights(A, a)
+        rho = A.sum(axis=0)
+        ev = _axsl(ax, slice(0, n, 2))
+
+        def nb(x, side):
+            """value of x at the F neighbour g- (side=-1) / g+ (side=+1) of each C point, 0 if none."""
+            out = np.zeros(x[ev].shape)
+            if side < 0:
+                out[_axsl(ax, slice(1, None))] = x[_axsl(ax, slice(1, n, 2))][_axsl(ax, slice(0, nc - 1))]
+            else:
+                src = x[_axsl(ax, slice(1, n, 2))]
+                out[_axsl(ax, slice(0, src.shape[ax]))] = src
+            return out
+        Pm = nb(wp, -1)      # P[g-, I] = w+(g-)
+        Pp = nb(wm, +1)      # P[g+, I] = w-(g+)
+        Ac = np.zeros((7,) + A[0][ev].shape)
+        lo_s, hi_s = 1 + 2 * a, 2 + 2 * a
+        Ac[lo_s] = A[lo_s][ev] * nb(wm, -1)
+        Ac[hi_s] = A[hi_s][ev] * nb(wp, +1)
+        for s in range(1, 7):
+            if s in (lo_s, hi_s):
+                continue
+            Ac[s] = A[s][ev] + Pm * nb(A[s], -1) + Pp * nb(A[s], +1)
+        Ac[0] = -Ac[1:].sum(axis=0) + rho[ev] + Pm * nb(rho, -1) + Pp * nb(rho, +1)
+        return Ac, (wm, wp)
+
+    def setup(self, A):
+        self.levels = [A]
+        self.W = []
+        for a in self.sched:
+            Ac, w = self.coarsen(self.levels[-1], a)
+            self.levels.append(Ac)
+            self.W.append(w)
+        import scipy.sparse.linalg as spla
+        M = to_csr(self.levels[-1][:, None, None])
+        self.coarse = spla.splu(M.tocsc()) if M.shape[0] > 1 else None
+        self.coarse_scalar = M[0, 0] if M.shape[0] == 1 else None
+        return self
+
+    def opcomplexity(self):
+        return sum(np.prod(l.shape[1:]) for l in self.levels) / np.prod(self.levels[0].shape[1:])
+
+    def restrict(self, r, lvl):
+        a = self.sched[lvl]
+        ax = 2 - a
+        n = r.shape[ax]
+        wm, wp = self.W[lvl]
+        rc = r[_axsl(ax, slice(0, n, 2))].copy()
+        odd = _axsl(ax, slice(1, n, 2))
+        t = wm[odd] * r[odd]                      # F point g contributes w-(g) r(g) to its left C
+        rc[_axsl(ax, slice(0, t.shape[ax]))] += t
+        t = wp[odd] * r[odd]                      # and w+(g) r(g) to its right C (if any)
+        k = min(t.shape[ax], rc.shape[ax] - 1)
+        rc[_axsl(ax, slice(1, 1 + k))] += t[_axsl(ax, slice(0, k))]
+        return rc
+
+    def prolong(self, ec, lvl, shape):
+        a = self.sched[lvl]
+        ax = 2 - a
+        n = shape[ax]
+        wm, wp = self.W[lvl]
+        e = np.zeros(shape)
+        e[_axsl(ax, slice(0, n, 2))] = ec
+        odd = _axsl(ax, slice(1, n, 2))
+        no = e[odd].shape[ax]
+        left = ec[_axsl(ax, slice(0, no))]
+        right = np.zeros(left.shape)
+        k = min(no, ec.shape[ax] - 1)
+        right[_axsl(ax, slice(0, k))] = ec[_axsl(ax, slice(1, 1 + k))]
+        e[odd] = wm[odd] * left + wp[odd] * right
+        return e
+
+    def _smooth(self, A, b, x):
+        return x + self.omega * (b - spmv_scalar(A, x)) / A[0]
+
+    def vcycle(self, b, lvl=0):
+        A = self.levels[lvl]
+        if lvl == len(self.levels) - 1:
+            if self.coarse is None:
+                return b / self.coarse_scalar
+            return self.coarse.solve(b.reshape(-1)).reshape(b.shape)
+        x = self.omega * b / A[0]
+        for _ in range(self.nu - 1):
+            x = self._smooth(A, b, x)
+        r = b - spmv_scalar(A, x)
+        ec = self.vcycle(self.restrict(r, lvl), lvl + 1)
+        x = x + self.prolong(ec, lvl, b.shape)
+        for _ in range(self.nu):
+            x = self._smooth(A, b, x)
+        return x
+
+
+# ------------------------------------------------------------------ stage 1 (CPR / CPTR)
+def decouple(J, kind, primary):
+    """Atilde = A_00 - D_0s D_ss^-1 A_s0 on the cell-interleaved stencil.
+
+    s = LAST field (preconditioners.py:358,1408).  QI: D = diagonal entries (:785-808,:1505-1543);
+    TI: column sums (:684-711,:1445-1503).  Returns (Atilde [7,len(primary),len(primary),...], d)
+    with d[q] = D_qs/D_ss per cell, used by apply as r_q = x_q - d[q] x_s (:894-895,:1559-1560)."""
+    b = J.shape[1]
+    s = b - 1
+    shape = J.shape[3:]
+    if kind == "No":
+        return J[:, primary][:, :, primary].copy(), None
+    if kind == "QI":
+        Dss = J[0, s, s]
+        D0s = [J[0, q, s] for q in primary]
+    elif kind == "TI":
+        ones = np.ones(shape)
+
+        def colsum(q):      # column sums of block (q, s): sum over rows i of A_qs[i, j]  == (A^T 1)_j
+            AT = J[:, q, s]
+            out = AT[0].copy()
+            for a in range(3):
+                if shape[2 - a] == 1:
+                    continue
+                lo, hi = _lo(a), _hi(a)
+                out[hi] += AT[2 + 2 * a][lo]      # row lo has entry in column hi
+                out[lo] += AT[1 + 2 * a][hi]
+            return out
+        Dss = colsum(s)
+        D0s = [colsum(q) for q in primary]
+    else:
+        raise ValueError("unknown decoupling " + str(kind))
+    d = [D / Dss for D in D0s]
+    At = np.zeros((7, len(primary), len(primary)) + shape)
+    for i, q in enumerate(primary):
+        for j, c in enumerate(primary):
+            At[:, i, j] = J[:, q, c] - d[i][None] * J[:, s, c]
+    return At, d
+
+
+class TwoStagePC:
+    """Composite multiplicative PC: y = B1 x; r = x - J y; y += B2 r (PCCOMPOSITE multiplicative,
+    singlephase.py:341-343).  B1 = CPR or CPTR stage 1, B2 = tiled block-ILU(0)."""
+
+    def __init__(self, prob, opts):
+        self.prob = prob
+        self.o = opts
+        n = prob.n
+        shape = prob.shape
+        st = [float(np.mean(prob.TK[a])) if n[a] > 1 else 0.0 for a in range(3)]
+        kw = dict(omega=opts["amg_omega"], min_cells=opts["amg_min_cells"], nu=opts["amg_nu"])
+        self.amg_p = SemiAMG(n, st, **kw)
+        self.amg_T = SemiAMG(n, [prob.G[a] if n[a] > 1 else 0.0 for a in range(3)], **kw) \
+            if opts["pc"] in ("cptr", "fieldsplit_cd") else None
+        self.ilu = TiledILU0(shape, opts["ilu_tile"])
+        self.vcycles = 0
+
+    def setup(self, J, Sm=None):
+        o = self.o
+        self.J = J
+        self.ilu.factor(J)
+        if o["pc"] == "cpr":
+            At, self.d = decouple(J, o["decoup"], [0])
+            self.amg_p.setup(At[:, 0, 0])
+        elif o["pc"] == "cptr":
+            # pc_cptr: decoup "No", fieldsplit Schur FULL on (p,T) with V(App), V(S~) (twophase.py:531-550)
+            At, self.d = decouple(J, o["decoup"], [0, 1])
+            self.At = At
+            self.amg_p.setup(At[:, 0, 0])
+            self.amg_T.setup(Sm)
+        else:
+            raise ValueError(o["pc"])
+
+    def stage1(self, x):
+        y = np.zeros_like(x)
+        o = self.o
+        s = x.shape[0] - 1
+        if o["pc"] == "cpr":
+            r = x[0] if self.d is None else x[0] - self.d[0] * x[s]
+            y[0] = self.amg_p.vcycle(r)
+            self.vcycles += 1
+        else:
+            r0 = x[0] if self.d is None else x[0] - self.d[0] * x[s]
+            r1 = x[1] if self.d is None else x[1] - self.d[1] * x[s]
+            At = self.At
+            # PCFIELDSPLIT schur FULL: y0 = K(A00) r0; y1 = K(S)(r1 - A10 y0); y0 = K(A00)(r0 - A01 y1)
+            y0 = self.amg_p.vcycle(r0)
+            y1 = self.amg_T.vcycle(r1 - spmv_scalar(At[:, 1, 0], y0))
+            y0 = self.amg_p.vcycle(r0 - spmv_scalar(At[:, 0, 1], y1))
+            y[0], y[1] = y0, y1
+            self.vcycles += 3
+        return y
+
+    def apply(self, x):
+        y = self.stage1(x)
+        r = x - spmv_block(self.J, y)
+        return y + self.ilu.solve(r)
+
+
+# ------------------------------------------------------------------ FGMRES
+def fgmres(matvec, pc, b, rtol=1e-8, atol=1e-50, restart=200, maxit=200, dot=None):
+    """Right-preconditioned flexible GMRES from x0 = 0 with classical Gram-Schmidt (PETSc default,
+    no refinement) and Givens-rotated Hessenberg; convergence on the recurrence residual norm,
+    ||r|| <= max(rtol*||b||, atol) (KSP default test).  Returns (x, its, reason, resnorms)."""
+    dot = dot or (lambda u, v: float(np.vdot(u, v).real))
+    x = np.zeros_like(b)
+    bnorm = np.sqrt(dot(b, b))
+    if bnorm == 0.0:
+        return x, 0, 2, [0.0]
+    tol = max(rtol * bnorm, atol)
+    its = 0
+    hist = [bnorm]
+    r = b.copy()
+    beta = bnorm
+    while True:
+        m = min(restart, maxit - its)
+        V = [r / beta]
+        Z = []
+        H = np.zeros((m + 1, m))
+        cs, sn = np.zeros(m), np.zeros(m)
+        g = np.zeros(m + 1)
+        g[0] = beta
+        k = 0
+        reason = 0
+        for j in range(m):
+            z = pc(V[j])
+            w = matvec(z)
+            Z.append(z)
+            h = np.array([dot(V[i], w) for i in range(j + 1)])
+            for i in range(j + 1):
+                w = w - h[i] * V[i]
+            hn = np.sqrt(dot(w, w))
+            H[:j + 1, j] = h
+            H[j + 1, j] = hn
+            for i in range(j):
+                t = cs[i] * H[i, j] + sn[i] * H[i + 1, j]
+                H[i + 1, j] = -sn[i] * H[i, j] + cs[i] * H[i + 1, j]
+                H[i, j] = t
+            d = np.hypot(H[j, j], H[j + 1, j])
+            cs[j], sn[j] = H[j, j] / d, H[j + 1, j] / d
+            H[j, j] = d
+            H[j + 1, j] = 0.0
+            g[j + 1] = -sn[j] * g[j]
+            g[j] = cs[j] * g[j]
+            its += 1
+            k = j + 1
+            res = abs(g[j + 1])
+            hist.append(res)
+            if res <= tol:
+                reason = 2          # KSP_CONVERGED_RTOL
+                break
+            if hn == 0.0:
+                reason = 2
+                break
+            V.append(w / hn)
+        yk = np.linalg.solve(np.triu(H[:k, :k]), g[:k]) if k else np.zeros(0)
+        for i in range(k):
+            x = x + yk[i] * Z[i]
+        if reason:
+            return x, its, reason, hist
+        if its >= maxit:
+            return x, its, -3, hist   # KSP_DIVERGED_ITS
+        r = b - matvec(x)
+        beta = np.sqrt(dot(r, r))
+        if beta <= tol:
+            return x, its, 2, hist
