@@ -1,0 +1,148 @@
+"""GPU parity tests: every stage of the HIP hot path against the CPU oracle on the same seeded inputs.
+
+Tolerances (float64 everywhere; differences come only from FMA contraction / summation order):
+  residual, Jacobian, S~ entries   rel <= 1e-11 of the largest entry of the same field/plane
+  SpMV, ILU solve, AMG V-cycle     rel <= 1e-10 in the 2-norm
+  FGMRES / Newton                  same iteration counts (+-1 Krylov), converged state rel <= 1e-8
+The reference itself (Firedrake/PETSc) cannot run here: parity vs the reference is unpinned, see
+oracle/__init__.py."""
+import numpy as np
+import pytest
+
+import cases
+
+pytestmark = pytest.mark.gpu
+
+
+def relmax(a, b):
+    return np.abs(a - b).max()/max(np.abs(b).max(), 1e-300)
+
+
+def rel2(a, b):
+    return np.linalg.norm((a - b).ravel())/max(np.linalg.norm(b.ravel()), 1e-300)
+
+
+def make(builder, opts, **kw):
+    from oracle.engine import OracleEngine
+    from thermalporous_amd.engine import HipEngine
+    spec, u0, *_ = builder(**kw)
+    o = OracleEngine(spec, opts)
+    h = HipEngine(spec, opts)
+    return spec, u0, o, h
+
+
+CASES = [
+    ("c1_1ph_2d", cases.c1_homogeneous, dict(N=12, nphase=1), dict(pc="cpr", ilu_tile=(1 << 30, 64, 1))),
+    ("c3_2ph_2d", cases.c3_spe10_2d, dict(Nx=14, Ny=19, nphase=2), dict(pc="cptr", ilu_tile=(1 << 30, 64, 1))),
+    ("c2_1ph_2d", cases.c3_spe10_2d, dict(Nx=14, Ny=19, nphase=1), dict(pc="cpr", decoup="QI", ilu_tile=(1 << 30, 64, 1))),
+    ("c4_2ph_3d", cases.c4_spe10_3d, dict(Nx=7, Ny=13, Nz=9, nphase=2), dict(pc="cptr")),
+    ("c4_1ph_3d", cases.c4_spe10_3d, dict(Nx=7, Ny=13, Nz=9, nphase=1), dict(pc="cpr", decoup="TI")),
+    ("c4_2ph_3d_cprQI", cases.c4_spe10_3d, dict(Nx=9, Ny=10, Nz=5, nphase=2), dict(pc="cpr", decoup="QI")),
+]
+
+
+@pytest.mark.parametrize("name,builder,kw,opts", CASES, ids=[c[0] for c in CASES])
+def test_assembly_parity(name, builder, kw, opts):
+    spec, u0, o, h = make(builder, opts, **kw)
+    u = cases.perturbed_state(spec, seed=3)
+    for e in (o, h):
+        e.set_old(u0)
+        e.set_dt(8640.0)
+        e.set_state(u)
+    Ro = o.residual()
+    Rh = h.residual()
+    for f in range(o.b):
+        assert relmax(Rh[f], Ro[f]) < 1e-11, (name, "residual field", f)
+    schur = opts["pc"] == "cptr"
+    out_o = o.jacobian(want_schur=schur)
+    out_h = h.jacobian(want_schur=schur)
+    Jo, Jh = (out_o[0], out_h[0]) if schur else (out_o, out_h)
+    b = o.b
+    for r in range(b):
+        for c in range(b):
+            scale = np.abs(Jo[:, r, c]).max()
+            if scale == 0.0:
+                assert np.abs(Jh[:, r, c]).max() == 0.0
+                continue
+            assert np.abs(Jh[:, r, c] - Jo[:, r, c]).max()/scale < 1e-11, (name, "J block", r, c)
+    if schur:
+        assert relmax(out_h[1], out_o[1]) < 1e-11
+    # well rates
+    ro, rh = o.well_rates(), h.well_rates()
+    for k in ro:
+        assert np.allclose(rh[k], ro[k], rtol=1e-12, atol=1e-30), k
+    h.close()
+
+
+@pytest.mark.parametrize("name,builder,kw,opts", CASES, ids=[c[0] for c in CASES])
+def test_linear_stages_parity(name, builder, kw, opts):
+    import oracle.linalg as la
+    spec, u0, o, h = make(builder, opts, **kw)
+    u = cases.perturbed_state(spec, seed=5, amp=0.3)
+    for e in (o, h):
+        e.set_old(u0)
+        e.set_dt(8640.0)
+        e.set_state(u)
+    schur = opts["pc"] == "cptr"
+    out = o.jacobian(want_schur=schur)
+    J, Sm = out if schur else (out, None)
+    h.jacobian()
+    rng = np.random.default_rng(11)
+    x = rng.standard_normal(J.shape[1:2] + J.shape[3:])
+    # MatMult
+    h.vec_set("x", x)
+    h.spmv("x", "y")
+    assert rel2(h.vec_get("y"), la.spmv_block(J, x)) < 1e-12
+    # PC set-up, then each stage
+    o.pc.setup(J, Sm)
+    h.pc_setup()
+    h.ilu_solve("x", "y")
+    assert rel2(h.vec_get("y"), o.pc.ilu.solve(x)) < 1e-10
+    h.amg_vcycle(0, "x", 0, "y", 0)
+    assert rel2(h.vec_get("y")[0], o.pc.amg_p.vcycle(x[0])) < 1e-10
+    if schur:
+        h.amg_vcycle(1, "x", 1, "y", 1)
+        assert rel2(h.vec_get("y")[1], o.pc.amg_T.vcycle(x[1])) < 1e-10
+    h.stage1_apply("x", "y")
+    assert rel2(h.vec_get("y"), o.pc.stage1(x)) < 1e-10
+    h.pc_apply("x", "y")
+    assert rel2(h.vec_get("y"), o.pc.apply(x)) < 1e-10
+    # FGMRES on J d = F
+    F = o.residual()
+    h.residual()
+    h.copy_residual_to("b")
+    its_h, reason_h, _ = h.fgmres("b", "d")
+    d_o, its_o, reason_o, _ = la.fgmres(lambda v: la.spmv_block(J, v), o.pc.apply, F, rtol=o.opts["ksp_rtol"],
+                                        maxit=o.opts["ksp_max_it"], restart=o.opts["ksp_restart"])
+    assert reason_h == reason_o == 2
+    assert abs(its_h - its_o) <= 1, (its_h, its_o)
+    assert rel2(h.vec_get("d"), d_o) < 1e-6
+    h.close()
+
+
+NEWTON = [
+    ("c1", cases.c1_homogeneous, dict(N=12, nphase=1), dict(pc="cpr", ilu_tile=(1 << 30, 64, 1)), 86400.0),
+    ("c3", cases.c3_spe10_2d, dict(Nx=14, Ny=19, nphase=2), dict(pc="cptr", ksp_rtol=1e-8, snes_max_it=25, ilu_tile=(1 << 30, 64, 1)), 864.0),
+    ("c4", cases.c4_spe10_3d, dict(Nx=7, Ny=13, Nz=9, nphase=2), dict(pc="cptr", ksp_rtol=1e-8, snes_max_it=25), 86.4),
+]
+
+
+@pytest.mark.parametrize("name,builder,kw,opts,dt", NEWTON, ids=[c[0] for c in NEWTON])
+def test_newton_parity(name, builder, kw, opts, dt):
+    spec, u0, o, h = make(builder, opts, **kw)
+    for e in (o, h):
+        e.set_state(u0)
+    for step in range(2):
+        for e in (o, h):
+            e.set_old(e.get_state() if e is o else None)
+            e.set_dt(dt)
+        ro = o.newton_solve()
+        rh = h.newton_solve()
+        assert ro["reason"] > 0 and rh["reason"] == ro["reason"], (ro, rh)
+        assert rh["nits"] == ro["nits"]
+        assert abs(rh["lits"] - ro["lits"]) <= max(2, 0.1*ro["lits"])
+        uo, uh = o.get_state(), h.get_state()
+        assert rel2(uh[0], uo[0]) < 1e-8 and rel2(uh[1], uo[1]) < 1e-8
+        if o.b == 3:
+            assert np.abs(uh[2] - uo[2]).max() < 1e-8
+    h.close()

@@ -1,0 +1,484 @@
+// extern "C" surface of libthermalporous_hip.so (declared in include/thermalporous_hip.h) and the RCCL
+// slab communication (halo exchange over xGMI point-to-point links, batched dot-product all-reduce).
+#include "tp_common.hpp"
+#include <rccl/rccl.h>
+#include <cmath>
+#include <algorithm>
+#include <map>
+
+namespace tp {
+
+static thread_local std::string g_err;
+void set_error(const std::string &msg) { g_err = msg; }
+
+#define TP_NCCL(call)                                                                          \
+    do {                                                                                       \
+        ncclResult_t r_ = (call);                                                              \
+        if (r_ != ncclSuccess)                                                                 \
+            throw tp::Error(std::string(#call) + " failed: " + ncclGetErrorString(r_));        \
+    } while (0)
+
+// One 1-cell halo plane per side along axis 2; each plane of each field is contiguous, so the
+// exchange is 2*nf send/recv pairs in one RCCL group on the compute stream (<= 2 neighbours, one
+// xGMI link each).
+void halo_exchange(tp_ctx *c, const GridDev &g, double *x, int nf, long fstride) {
+    if (!c->comm) return;
+    ncclComm_t comm = (ncclComm_t)c->comm;
+    const int lo = c->grid.rank - 1, hi = c->grid.rank + 1;
+    TP_NCCL(ncclGroupStart());
+    for (int f = 0; f < nf; ++f) {
+        double *p = x + (long)f * fstride;
+        if (g.nb_lo) {
+            TP_NCCL(ncclSend(p + g.np, g.np, ncclDouble, lo, comm, c->stream));                    // first owned plane
+            TP_NCCL(ncclRecv(p, g.np, ncclDouble, lo, comm, c->stream));                           // lower halo
+        }
+        if (g.nb_hi) {
+            TP_NCCL(ncclSend(p + g.np * g.n2, g.np, ncclDouble, hi, comm, c->stream));             // last owned plane
+            TP_NCCL(ncclRecv(p + g.np * (g.n2 + 1), g.np, ncclDouble, hi, comm, c->stream));       // upper halo
+        }
+    }
+    TP_NCCL(ncclGroupEnd());
+}
+
+void allreduce_sum(tp_ctx *c, double *dev, int n) {
+    if (!c->comm || n <= 0) return;
+    TP_NCCL(ncclAllReduce(dev, dev, n, ncclDouble, ncclSum, (ncclComm_t)c->comm, c->stream));
+}
+
+}  // namespace tp
+
+tp_ctx::~tp_ctx() {
+    for (auto *v : vecs) delete v;
+    delete amg_p;
+    delete amg_T;
+    if (comm) ncclCommDestroy((ncclComm_t)comm);
+    if (ev0) (void)hipEventDestroy(ev0);
+    if (ev1) (void)hipEventDestroy(ev1);
+    if (stream) (void)hipStreamDestroy(stream);
+}
+
+using namespace tp;
+
+#define TP_API_BEGIN try {
+#define TP_API_END                                   \
+    return 0;                                        \
+    }                                                \
+    catch (const std::exception &e) {                \
+        tp::set_error(e.what());                     \
+        return -1;                                   \
+    }                                                \
+    catch (...) {                                    \
+        tp::set_error("unknown C++ exception");      \
+        return -1;                                   \
+    }
+
+static void derive_params(tp_ctx *c) {
+    const tp_params &p = c->prm;
+    DevPrm &d = c->dprm;
+    d.ko = p.ko; d.kw = p.kw; d.kr = p.kr; d.c_v_w = p.c_v_w; d.c_v_o = p.c_v_o; d.c_r = p.c_r;
+    d.rho_r = p.rho_r; d.T_inj = p.T_inj; d.g = p.g; d.U = p.U;
+    const double SG = 141.5 / (p.API + 131.5);               // physicalparameters.py:39-40
+    d.rho_ref = SG * 999.0;
+    d.mu_o_coef = 1e-3 * std::pow(10.0, -0.8021 * p.API + 23.8765);   // :52-57
+    d.mu_o_exp = 0.31458 * p.API + (-9.21592);
+    if (c->nph == 2) {                                        // twophase.py:142-147
+        d.w0 = p.T_prod;
+        d.w2 = p.T_prod * (p.c_v_w * (1.0 - p.S_o) + p.c_v_o * p.S_o);
+    } else {                                                  // m_w = 1 (singlephase.py:26,112-115)
+        d.w0 = 1.0;
+        d.w2 = 0.0;
+    }
+}
+
+static DBuf<double> &vec_of(tp_ctx *c, int id) {
+    TP_REQUIRE(id >= 0 && id < (int)c->vecs.size(), "bad vector id");
+    return *c->vecs[id];
+}
+
+extern "C" {
+
+const char *tp_last_error(void) { return tp::g_err.c_str(); }
+int tp_version(void) { return 100; }
+
+int tp_create(const tp_grid *grid, const tp_params *prm, const tp_options *opt, int device, tp_ctx **out) {
+    TP_API_BEGIN
+    TP_REQUIRE(grid && prm && opt && out, "null argument");
+    TP_REQUIRE(grid->n0 >= 1 && grid->n1 >= 1 && grid->n2 >= 1, "empty grid");
+    TP_REQUIRE(grid->nphase == 1 || grid->nphase == 2, "nphase must be 1 or 2");
+    TP_REQUIRE(grid->off2 >= 0 && grid->off2 + grid->n2 <= grid->gn2, "slab outside the global grid");
+    TP_REQUIRE((long)grid->n0 * grid->n1 * (grid->n2 + 2) < (1L << 31), "slab too large for int32 block indices");
+    int ndev = 0;
+    TP_HIP(hipGetDeviceCount(&ndev));
+    TP_REQUIRE(ndev > 0, "no HIP device: the thermalporous hot path has no CPU fallback");
+    TP_REQUIRE(device >= 0 && device < ndev, "bad device ordinal");
+    TP_HIP(hipSetDevice(device));
+    tp_ctx *c = new tp_ctx();
+    c->grid = *grid; c->prm = *prm; c->opt = *opt; c->device = device;
+    c->nph = grid->nphase; c->b = grid->nphase + 1;
+    c->g = make_grid(grid->n0, grid->n1, grid->n2, grid->gn2, grid->off2);
+    c->vol = grid->h[0] * grid->h[1] * grid->h[2];
+    derive_params(c);
+    TP_HIP(hipStreamCreate(&c->stream));
+    TP_HIP(hipEventCreate(&c->ev0));
+    TP_HIP(hipEventCreate(&c->ev1));
+    const size_t nt = (size_t)c->g.ntot, B = (size_t)c->b;
+    c->phi.alloc(nt); c->kTs.alloc(nt);
+    for (int a = 0; a < 3; ++a) { c->K[a].alloc(nt); c->TK[a].alloc(nt); }
+    c->u.alloc(B * nt); c->u_old.alloc(B * nt); c->acc_old.alloc(B * nt); c->R.alloc(B * nt);
+    c->J.alloc(7 * B * B * nt);
+    if (opt->pc_kind == 1) c->Sm.alloc(7 * nt);
+    *out = c;
+    TP_API_END
+}
+
+int tp_destroy(tp_ctx *ctx) {
+    TP_API_BEGIN
+    if (ctx) {
+        (void)hipSetDevice(ctx->device);
+        (void)hipDeviceSynchronize();
+        delete ctx;
+    }
+    TP_API_END
+}
+
+int tp_set_options(tp_ctx *c, const tp_options *opt) {
+    TP_API_BEGIN
+    TP_REQUIRE(c && opt, "null argument");
+    const bool tile_changed = opt->ilu_t1 != c->opt.ilu_t1 || opt->ilu_t2 != c->opt.ilu_t2;
+    const bool amg_changed = opt->amg_min_cells != c->opt.amg_min_cells || opt->pc_kind != c->opt.pc_kind;
+    c->opt = *opt;
+    if (tile_changed) c->ilu.slots = 0;
+    if (amg_changed) { delete c->amg_p; c->amg_p = nullptr; delete c->amg_T; c->amg_T = nullptr; }
+    if (opt->pc_kind == 1 && c->Sm.n == 0) c->Sm.alloc((size_t)7 * c->g.ntot);
+    c->pc_ready = false;
+    TP_API_END
+}
+
+int tp_comm_unique_id(void *id128) {
+    TP_API_BEGIN
+    static_assert(sizeof(ncclUniqueId) == 128, "ncclUniqueId size");
+    ncclUniqueId id;
+    TP_NCCL(ncclGetUniqueId(&id));
+    std::memcpy(id128, &id, sizeof(id));
+    TP_API_END
+}
+
+int tp_comm_init(tp_ctx *c, const void *id128) {
+    TP_API_BEGIN
+    TP_REQUIRE(c && id128, "null argument");
+    TP_REQUIRE(c->grid.nranks > 1, "tp_comm_init on a single-slab context");
+    TP_HIP(hipSetDevice(c->device));
+    ncclUniqueId id;
+    std::memcpy(&id, id128, sizeof(id));
+    ncclComm_t comm;
+    TP_NCCL(ncclCommInitRank(&comm, c->grid.nranks, id, c->grid.rank));
+    c->comm = (ncclComm *)comm;
+    TP_API_END
+}
+
+int tp_set_field(tp_ctx *c, const char *name, const double *host, int64_t n) {
+    TP_API_BEGIN
+    TP_REQUIRE(c && name && host, "null argument");
+    TP_REQUIRE(n == c->g.ntot, "field must have n0*n1*(n2+2) entries (slab with halo planes)");
+    DBuf<double> *dst = nullptr;
+    const std::string s(name);
+    if (s == "phi") dst = &c->phi;
+    else if (s == "kT") dst = &c->kTs;
+    else if (s == "K0") dst = &c->K[0];
+    else if (s == "K1") dst = &c->K[1];
+    else if (s == "K2") dst = &c->K[2];
+    TP_REQUIRE(dst, "unknown field name (phi, kT, K0, K1, K2)");
+    TP_HIP(hipMemcpy(dst->p, host, sizeof(double) * n, hipMemcpyHostToDevice));
+    c->fields_ready = false;
+    TP_API_END
+}
+
+int tp_finalize_fields(tp_ctx *c) {
+    TP_API_BEGIN
+    compute_trans(c);
+    TP_HIP(hipStreamSynchronize(c->stream));
+    c->fields_ready = true;
+    delete c->amg_p; c->amg_p = nullptr;
+    delete c->amg_T; c->amg_T = nullptr;
+    TP_API_END
+}
+
+int tp_set_sources(tp_ctx *c, int32_t n, const tp_source *entries) {
+    TP_API_BEGIN
+    TP_REQUIRE(c && (n == 0 || entries), "null argument");
+    std::vector<tp_source> v(entries, entries + n);
+    const GridDev &g = c->g;
+    for (auto &e : v) {
+        TP_REQUIRE(e.cell >= g.np && e.cell < g.np + g.nown, "source cell is not an owned cell of this slab");
+        TP_REQUIRE(e.kind >= 0 && e.kind <= 2, "source kind must be 0 (prod), 1 (inj) or 2 (heater)");
+    }
+    std::stable_sort(v.begin(), v.end(), [](const tp_source &a, const tp_source &b) { return a.cell < b.cell; });
+    std::vector<int> start;
+    for (int i = 0; i < n; ++i)
+        if (i == 0 || v[i].cell != v[i - 1].cell) start.push_back(i);
+    c->nsrc = n;
+    c->nsrc_groups = (int)start.size();
+    start.push_back(n);
+    c->src.alloc(std::max(1, n));
+    c->src_start.alloc(start.size());
+    c->rates.alloc((size_t)3 * std::max(1, n));
+    if (n) TP_HIP(hipMemcpy(c->src.p, v.data(), sizeof(tp_source) * n, hipMemcpyHostToDevice));
+    TP_HIP(hipMemcpy(c->src_start.p, start.data(), sizeof(int) * start.size(), hipMemcpyHostToDevice));
+    TP_API_END
+}
+
+int tp_set_state(tp_ctx *c, const double *u_host) {
+    TP_API_BEGIN
+    TP_REQUIRE(c && u_host, "null argument");
+    TP_HIP(hipMemcpy(c->u.p, u_host, sizeof(double) * c->u.n, hipMemcpyHostToDevice));
+    TP_API_END
+}
+
+int tp_get_state(tp_ctx *c, double *u_host) {
+    TP_API_BEGIN
+    TP_REQUIRE(c && u_host, "null argument");
+    TP_HIP(hipStreamSynchronize(c->stream));
+    TP_HIP(hipMemcpy(u_host, c->u.p, sizeof(double) * c->u.n, hipMemcpyDeviceToHost));
+    TP_API_END
+}
+
+int tp_set_old_state(tp_ctx *c, const double *u_host) {
+    TP_API_BEGIN
+    TP_REQUIRE(c, "null argument");
+    TP_REQUIRE(c->fields_ready, "fields not finalised");
+    if (u_host) TP_HIP(hipMemcpy(c->u_old.p, u_host, sizeof(double) * c->u.n, hipMemcpyHostToDevice));
+    else vec_copy(c, c->u.p, c->u_old.p, (long)c->u.n);
+    accum_old(c);
+    c->have_old = true;
+    TP_API_END
+}
+
+int tp_set_dt(tp_ctx *c, double dt) {
+    TP_API_BEGIN
+    TP_REQUIRE(c && dt > 0.0, "dt must be positive");
+    c->dt = dt;
+    TP_API_END
+}
+
+int tp_residual(tp_ctx *c, double *norm2_out) {
+    TP_API_BEGIN
+    if (c->comm) halo_exchange(c, c->g, c->u.p, c->b, c->g.ntot);
+    assemble(c, false, false);
+    const double n = norm2(c, c->b, c->R.p);
+    if (norm2_out) *norm2_out = n;
+    TP_API_END
+}
+
+int tp_jacobian(tp_ctx *c) {
+    TP_API_BEGIN
+    if (c->comm) halo_exchange(c, c->g, c->u.p, c->b, c->g.ntot);
+    assemble(c, true, c->opt.pc_kind == 1);
+    c->pc_ready = false;
+    TP_HIP(hipStreamSynchronize(c->stream));
+    TP_API_END
+}
+
+int tp_get_residual(tp_ctx *c, double *host) {
+    TP_API_BEGIN
+    TP_HIP(hipStreamSynchronize(c->stream));
+    TP_HIP(hipMemcpy(host, c->R.p, sizeof(double) * c->R.n, hipMemcpyDeviceToHost));
+    TP_API_END
+}
+
+int tp_export_jacobian(tp_ctx *c, double *host) {
+    TP_API_BEGIN
+    TP_REQUIRE(c->jac_ready, "Jacobian not assembled");
+    TP_HIP(hipStreamSynchronize(c->stream));
+    TP_HIP(hipMemcpy(host, c->J.p, sizeof(double) * c->J.n, hipMemcpyDeviceToHost));
+    TP_API_END
+}
+
+int tp_export_schur(tp_ctx *c, double *host) {
+    TP_API_BEGIN
+    TP_REQUIRE(c->Sm.n > 0 && c->jac_ready, "S~ not assembled (pc_cptr only)");
+    TP_HIP(hipStreamSynchronize(c->stream));
+    TP_HIP(hipMemcpy(host, c->Sm.p, sizeof(double) * c->Sm.n, hipMemcpyDeviceToHost));
+    TP_API_END
+}
+
+int tp_well_rates(tp_ctx *c, double *rate, double *water_rate, double *oil_rate) {
+    TP_API_BEGIN
+    if (c->nsrc == 0) return 0;
+    well_rates(c);
+    TP_HIP(hipStreamSynchronize(c->stream));
+    const size_t n = c->nsrc;
+    if (rate) TP_HIP(hipMemcpy(rate, c->rates.p, sizeof(double) * n, hipMemcpyDeviceToHost));
+    if (water_rate) TP_HIP(hipMemcpy(water_rate, c->rates.p + n, sizeof(double) * n, hipMemcpyDeviceToHost));
+    if (oil_rate) TP_HIP(hipMemcpy(oil_rate, c->rates.p + 2 * n, sizeof(double) * n, hipMemcpyDeviceToHost));
+    TP_API_END
+}
+
+int tp_vec_create(tp_ctx *c, int32_t *id) {
+    TP_API_BEGIN
+    auto *v = new DBuf<double>();
+    v->alloc((size_t)c->b * c->g.ntot);
+    c->vecs.push_back(v);
+    *id = (int32_t)c->vecs.size() - 1;
+    TP_API_END
+}
+
+int tp_vec_set(tp_ctx *c, int32_t id, const double *host) {
+    TP_API_BEGIN
+    DBuf<double> &v = vec_of(c, id);
+    TP_HIP(hipMemcpy(v.p, host, sizeof(double) * v.n, hipMemcpyHostToDevice));
+    TP_API_END
+}
+
+int tp_vec_get(tp_ctx *c, int32_t id, double *host) {
+    TP_API_BEGIN
+    DBuf<double> &v = vec_of(c, id);
+    TP_HIP(hipStreamSynchronize(c->stream));
+    TP_HIP(hipMemcpy(host, v.p, sizeof(double) * v.n, hipMemcpyDeviceToHost));
+    TP_API_END
+}
+
+int tp_vec_copy_residual(tp_ctx *c, int32_t id) {
+    TP_API_BEGIN
+    vec_copy(c, c->R.p, vec_of(c, id).p, (long)c->R.n);
+    TP_API_END
+}
+
+int tp_spmv(tp_ctx *c, int32_t x, int32_t y) {
+    TP_API_BEGIN
+    TP_REQUIRE(c->jac_ready, "Jacobian not assembled");
+    TP_REQUIRE(x != y, "tp_spmv: x and y must differ");
+    if (c->comm) halo_exchange(c, c->g, vec_of(c, x).p, c->b, c->g.ntot);
+    spmv_block(c, c->J.p, vec_of(c, x).p, vec_of(c, y).p);
+    TP_API_END
+}
+
+int tp_pc_setup(tp_ctx *c) {
+    TP_API_BEGIN
+    pc_setup(c);
+    TP_API_END
+}
+
+int tp_pc_apply(tp_ctx *c, int32_t x, int32_t y) {
+    TP_API_BEGIN
+    TP_REQUIRE(x != y, "tp_pc_apply: x and y must differ");
+    pc_apply(c, vec_of(c, x).p, vec_of(c, y).p);
+    TP_API_END
+}
+
+int tp_stage1_update(tp_ctx *c) {
+    TP_API_BEGIN
+    // CPRStage1PC.update: assemble_blocks + create_decoup + pc_schur.setOperators (AMG set-up).
+    // Here PCSetUp of both stages is one call; kept separate in the API for the PCBase mirror.
+    pc_setup(c);
+    TP_API_END
+}
+
+int tp_stage1_apply(tp_ctx *c, int32_t x, int32_t y) {
+    TP_API_BEGIN
+    TP_REQUIRE(c->pc_ready, "stage 1 not set up");
+    TP_REQUIRE(x != y, "x and y must differ");
+    stage1_apply(c, vec_of(c, x).p, vec_of(c, y).p);
+    TP_API_END
+}
+
+int tp_ilu0_factor(tp_ctx *c) {
+    TP_API_BEGIN
+    ilu_factor(c);
+    TP_API_END
+}
+
+int tp_ilu0_solve(tp_ctx *c, int32_t x, int32_t y) {
+    TP_API_BEGIN
+    TP_REQUIRE(x != y, "x and y must differ");
+    ilu_solve(c, vec_of(c, x).p, vec_of(c, y).p, nullptr);
+    TP_API_END
+}
+
+int tp_amg_setup(tp_ctx *c, int32_t which) {
+    TP_API_BEGIN
+    (void)which;
+    pc_setup(c);
+    TP_API_END
+}
+
+int tp_amg_vcycle(tp_ctx *c, int32_t which, int32_t field_b, int32_t b, int32_t field_x, int32_t x) {
+    TP_API_BEGIN
+    TP_REQUIRE(c->pc_ready, "AMG not set up");
+    Amg *amg = which == 0 ? c->amg_p : c->amg_T;
+    TP_REQUIRE(amg, "this AMG hierarchy does not exist for the selected preconditioner");
+    TP_REQUIRE(field_b >= 0 && field_b < c->b && field_x >= 0 && field_x < c->b, "bad field index");
+    TP_REQUIRE(!(b == x && field_b == field_x), "b and x must differ");
+    amg_vcycle(c, amg, vec_of(c, b).p + (long)field_b * c->g.ntot, vec_of(c, x).p + (long)field_x * c->g.ntot);
+    TP_API_END
+}
+
+int tp_schur_apply(tp_ctx *c, int32_t x, int32_t y) {
+    TP_API_BEGIN
+    TP_REQUIRE(c->pc_ready && c->amg_T, "S~ AMG not set up (pc_cptr only)");
+    TP_REQUIRE(x != y, "x and y must differ");
+    amg_vcycle(c, c->amg_T, vec_of(c, x).p + c->g.ntot, vec_of(c, y).p + c->g.ntot);
+    TP_API_END
+}
+
+int tp_fgmres(tp_ctx *c, int32_t b, int32_t x, int32_t *its, int32_t *reason, double *rnorm) {
+    TP_API_BEGIN
+    TP_REQUIRE(b != x, "b and x must differ");
+    if (!c->pc_ready) pc_setup(c);
+    int it = 0;
+    double rn = 0.0;
+    const int r = fgmres(c, vec_of(c, b).p, vec_of(c, x).p, &it, &rn);
+    if (its) *its = it;
+    if (reason) *reason = r;
+    if (rnorm) *rnorm = rn;
+    TP_API_END
+}
+
+int tp_newton_solve(tp_ctx *c, tp_solve_info *info) {
+    TP_API_BEGIN
+    TP_REQUIRE(c && info, "null argument");
+    newton(c, info);
+    TP_HIP(hipStreamSynchronize(c->stream));
+    TP_API_END
+}
+
+int tp_time_kernel(tp_ctx *c, int32_t which, int32_t reps, double *ms_avg) {
+    TP_API_BEGIN
+    TP_REQUIRE(reps > 0 && ms_avg, "bad arguments");
+    const size_t nv = (size_t)c->b * c->g.ntot;
+    if (c->w1.n < nv) { c->w1.alloc(nv); c->w2.alloc(nv); c->w3.alloc(nv); c->w4.alloc(nv); }
+    if (c->dx.n < nv) c->dx.alloc(nv);
+    if (which != 3) TP_REQUIRE(c->jac_ready, "Jacobian not assembled");
+    if (which == 1 || which == 2 || which == 4) TP_REQUIRE(c->pc_ready, "preconditioner not set up");
+    auto run = [&]() {
+        switch (which) {
+            case 0: spmv_block(c, c->J.p, c->R.p, c->w2.p); break;
+            case 1: ilu_solve(c, c->R.p, c->w2.p, nullptr); break;
+            case 2: amg_vcycle(c, c->amg_p, c->R.p, c->w2.p); break;
+            case 3: assemble(c, true, c->opt.pc_kind == 1); break;
+            case 4: pc_apply(c, c->R.p, c->dx.p); break;
+            default: throw Error("unknown kernel id");
+        }
+    };
+    run();                                                      // warm-up
+    TP_HIP(hipEventRecord(c->ev0, c->stream));
+    for (int i = 0; i < reps; ++i) run();
+    TP_HIP(hipEventRecord(c->ev1, c->stream));
+    TP_HIP(hipEventSynchronize(c->ev1));
+    float ms = 0.f;
+    TP_HIP(hipEventElapsedTime(&ms, c->ev0, c->ev1));
+    *ms_avg = (double)ms / reps;
+    TP_API_END
+}
+
+int tp_amg_info(tp_ctx *c, int32_t which, int32_t *nlevels, double *op_complexity) {
+    TP_API_BEGIN
+    Amg *amg = which == 0 ? c->amg_p : c->amg_T;
+    TP_REQUIRE(amg, "AMG hierarchy not built");
+    if (nlevels) *nlevels = (int)amg->lv.size();
+    double s = 0.0;
+    for (auto *l : amg->lv) s += (double)l->g.nown;
+    if (op_complexity) *op_complexity = s / (double)amg->lv[0]->g.nown;
+    TP_API_END
+}
+
+}  // extern "C"

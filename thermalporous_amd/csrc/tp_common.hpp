@@ -1,0 +1,196 @@
+// Shared host-side declarations of libthermalporous_hip (context, buffers, launch helpers).
+#pragma once
+#include <hip/hip_runtime.h>
+#include <cstdint>
+#include <cstdio>
+#include <cstring>
+#include <string>
+#include <vector>
+#include <stdexcept>
+#include "../../include/thermalporous_hip.h"
+
+struct ncclComm;
+
+namespace tp {
+
+void set_error(const std::string &msg);
+
+struct Error : std::runtime_error {
+    using std::runtime_error::runtime_error;
+};
+
+#define TP_HIP(call)                                                                             \
+    do {                                                                                         \
+        hipError_t e_ = (call);                                                                  \
+        if (e_ != hipSuccess)                                                                    \
+            throw tp::Error(std::string(#call) + " failed: " + hipGetErrorString(e_) + " at " +  \
+                            __FILE__ + ":" + std::to_string(__LINE__));                          \
+    } while (0)
+
+#define TP_REQUIRE(cond, msg)                                                                    \
+    do {                                                                                         \
+        if (!(cond)) throw tp::Error(std::string(msg) + " [" #cond "]");                         \
+    } while (0)
+
+// Device view of the slab grid, passed by value to kernels.
+struct GridDev {
+    int n0, n1, n2;        // owned
+    int gn2, off2;         // global extent/offset along axis 2
+    long np;               // n0*n1 (plane)
+    long nown;             // np*n2
+    long ntot;             // np*(n2+2)
+    int nb_lo, nb_hi;      // 1 if a neighbouring slab exists below/above (halo is live)
+};
+
+inline GridDev make_grid(int n0, int n1, int n2, int gn2, int off2) {
+    GridDev g;
+    g.n0 = n0; g.n1 = n1; g.n2 = n2; g.gn2 = gn2; g.off2 = off2;
+    g.np = (long)n0 * n1; g.nown = g.np * n2; g.ntot = g.np * (n2 + 2);
+    g.nb_lo = off2 > 0; g.nb_hi = off2 + n2 < gn2;
+    return g;
+}
+
+// Scalar 7-point stencil operator: slot s lives at base + s*slot_stride (doubles).
+struct Stencil {
+    double *base = nullptr;
+    long slot_stride = 0;
+    __host__ __device__ const double *slot(int s) const { return base + (long)s * slot_stride; }
+    __host__ __device__ double *slot(int s) { return base + (long)s * slot_stride; }
+};
+
+// Derived closure constants (device copy of tp_params + precomputed factors).
+struct DevPrm {
+    double ko, kw, kr, c_v_w, c_v_o, c_r, rho_r, T_inj, g, U;
+    double rho_ref, mu_o_coef, mu_o_exp;   // oil_rho / oil_mu (physicalparameters.py:37-57)
+    double w0, w2;                          // equation weights (twophase.py:142-147)
+};
+
+template <class T>
+struct DBuf {
+    T *p = nullptr;
+    size_t n = 0;
+    void alloc(size_t n_) {
+        free();
+        n = n_;
+        if (n) {
+            TP_HIP(hipMalloc((void **)&p, n * sizeof(T)));
+            TP_HIP(hipMemset(p, 0, n * sizeof(T)));
+        }
+    }
+    void free() {
+        if (p) (void)hipFree(p);
+        p = nullptr;
+        n = 0;
+    }
+    ~DBuf() { free(); }
+    DBuf() = default;
+    DBuf(const DBuf &) = delete;
+    DBuf &operator=(const DBuf &) = delete;
+};
+
+struct AmgLevel {
+    GridDev g;
+    DBuf<double> A;        // 7 planes (levels >= 1); level 0 uses an external stencil view
+    Stencil op;
+    DBuf<double> invd;     // omega / diag
+    DBuf<double> wm, wp;   // interpolation weights of F points along `axis`
+    DBuf<double> b, x, x2, r, e;
+    int axis = -1;         // coarsening axis towards the next level (-1: coarsest)
+};
+
+struct Amg {
+    std::vector<AmgLevel *> lv;
+    DBuf<double> coarse_inv;   // dense inverse on the coarsest grid
+    int ncoarse = 0;
+    std::vector<int> sched;
+    ~Amg() { for (auto *l : lv) delete l; }
+};
+
+struct IluData {
+    int t1 = 8, t2 = 8, nt1 = 0, nt2 = 0, ntiles = 0, nsteps = 0;
+    DBuf<double> fwd, bwd, ytmp;   // streaming factor data in consumption order
+    long slots = 0;                // ntiles*nsteps*64
+};
+
+}  // namespace tp
+
+struct tp_ctx {
+    tp_grid grid;
+    tp_params prm;
+    tp_options opt;
+    tp::GridDev g;
+    tp::DevPrm dprm;
+    int nph = 1, b = 2, device = 0;
+    hipStream_t stream = nullptr;
+    hipEvent_t ev0 = nullptr, ev1 = nullptr;
+    double dt = 0.0, vol = 0.0;
+    bool fields_ready = false, have_old = false, jac_ready = false, pc_ready = false;
+    // fields
+    tp::DBuf<double> phi, K[3], kTs, TK[3];
+    // state
+    tp::DBuf<double> u, u_old, acc_old, R, J, Sm;
+    // sources
+    tp::DBuf<tp_source> src;
+    tp::DBuf<int> src_start;      // groups of entries sharing a cell
+    int nsrc = 0, nsrc_groups = 0;
+    tp::DBuf<double> rates;       // 3*nsrc
+    // linear algebra
+    std::vector<tp::DBuf<double> *> vecs;
+    tp::DBuf<double> At;          // decoupled primary block (QI/TI); planes as in J with b' = nprimary
+    tp::DBuf<double> dcoef;       // decoupling coefficients d_q per cell (nprimary planes)
+    tp::Stencil opA00, opA01, opA10;   // views used by stage 1
+    tp::Amg *amg_p = nullptr, *amg_T = nullptr;
+    tp::IluData ilu;
+    // FGMRES workspace
+    tp::DBuf<double> V, Z, gs_partial, gs_h, red_out;
+    int gs_cap = 0;
+    std::vector<double> hostbuf;
+    // scratch vectors for PC apply
+    tp::DBuf<double> w1, w2, w3, w4, dx;
+    // comm
+    ncclComm *comm = nullptr;
+    long vcycles = 0;
+    ~tp_ctx();
+};
+
+namespace tp {
+// ---- launch wrappers implemented in the .hip files ------------------------------------------------
+// assembly
+void compute_trans(tp_ctx *c);
+void accum_old(tp_ctx *c);
+void assemble(tp_ctx *c, bool want_jac, bool want_schur);
+void well_rates(tp_ctx *c);
+// vectors / reductions (vectors are b field planes of ntot; reductions run over owned cells only)
+void vec_zero(tp_ctx *c, double *x, long n);
+void vec_copy(tp_ctx *c, const double *x, double *y, long n);
+void vec_axpy_owned(tp_ctx *c, int nf, double a, const double *x, double *y);            // y += a x
+void vec_scale_to(tp_ctx *c, int nf, double a, const double *x, double *y);             // y = a x (owned)
+void multi_dot(tp_ctx *c, int nf, const double *V, long vstride, int k, const double *w, const double *w2,
+               double *host_out);   // host_out[i] = <V_i, w>, i<k ; host_out[k] = <w2,w2> if w2
+void multi_axpy(tp_ctx *c, int nf, const double *V, long vstride, int k, const double *hcoef_host, double sign,
+                double *w);          // w += sign * sum_i h_i V_i
+double norm2(tp_ctx *c, int nf, const double *x);
+// stencil operators
+void spmv_block(tp_ctx *c, const double *J, const double *x, double *y);                 // y = J x
+void resid_block_cols(tp_ctx *c, const double *J, const double *x, const double *y, int ncols, double *r);  // r = x - J[:, :ncols] y
+void spmv_scalar(tp_ctx *c, const GridDev &g, const Stencil &A, const double *x, double *y, double alpha, const double *z);  // y = z + alpha*A x (z may be null)
+void decouple(tp_ctx *c);
+void stage1_rhs(tp_ctx *c, const double *x, int q, double *out);                        // out = x_q - d_q x_s
+// ILU
+void ilu_setup(tp_ctx *c);
+void ilu_factor(tp_ctx *c);
+void ilu_solve(tp_ctx *c, const double *r, double *x, const double *addto);             // x = addto + M^-1 r
+// AMG
+void amg_build(tp_ctx *c, Amg *&amg, const double strength[3]);
+void amg_setup(tp_ctx *c, Amg *amg, const Stencil &A0);
+void amg_vcycle(tp_ctx *c, Amg *amg, const double *b, double *x);
+// comm
+void halo_exchange(tp_ctx *c, const GridDev &g, double *x, int nf, long fstride);
+void allreduce_sum(tp_ctx *c, double *dev, int n);
+// solver
+void pc_setup(tp_ctx *c);
+void stage1_apply(tp_ctx *c, const double *x, double *y);
+void pc_apply(tp_ctx *c, const double *x, double *y);
+int fgmres(tp_ctx *c, const double *b, double *x, int *its, double *rnorm);
+void newton(tp_ctx *c, tp_solve_info *info);
+}  // namespace tp

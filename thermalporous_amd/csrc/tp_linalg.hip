@@ -1,0 +1,318 @@
+// Vector kernels, reductions and stencil mat-vecs (what PETSc Vec*/MatMult do in the reference:
+// SURVEY.md 2.2 N3, N4, N9, N10).  All HBM-bound; one thread per owned cell, consecutive lanes on
+// consecutive cells, every matrix plane streamed exactly once per product.
+#include "tp_common.hpp"
+
+namespace tp {
+
+static inline dim3 grid_for(long n, int bs = 256) { return dim3((unsigned)((n + bs - 1) / bs)); }
+
+// ---- elementwise ---------------------------------------------------------------------------------
+__global__ void k_zero(double *x, long n) {
+    const long i = (long)blockIdx.x * blockDim.x + threadIdx.x;
+    if (i < n) x[i] = 0.0;
+}
+__global__ void k_copy(const double *x, double *y, long n) {
+    const long i = (long)blockIdx.x * blockDim.x + threadIdx.x;
+    if (i < n) y[i] = x[i];
+}
+// y[f][c] (+)= a*x[f][c] over owned cells of nf fields
+template <bool ACC>
+__global__ void k_axpy_owned(GridDev g, int nf, double a, const double *x, double *y) {
+    const long t = (long)blockIdx.x * blockDim.x + threadIdx.x;
+    if (t >= g.nown * nf) return;
+    const long f = t / g.nown, i = t - f * g.nown;
+    const long c = f * g.ntot + g.np + i;
+    y[c] = ACC ? y[c] + a * x[c] : a * x[c];
+}
+
+void vec_zero(tp_ctx *c, double *x, long n) {
+    hipLaunchKernelGGL(k_zero, grid_for(n), dim3(256), 0, c->stream, x, n);
+}
+void vec_copy(tp_ctx *c, const double *x, double *y, long n) {
+    hipLaunchKernelGGL(k_copy, grid_for(n), dim3(256), 0, c->stream, x, y, n);
+}
+void vec_axpy_owned(tp_ctx *c, int nf, double a, const double *x, double *y) {
+    hipLaunchKernelGGL(k_axpy_owned<true>, grid_for(c->g.nown * nf), dim3(256), 0, c->stream, c->g, nf, a, x, y);
+}
+void vec_scale_to(tp_ctx *c, int nf, double a, const double *x, double *y) {
+    hipLaunchKernelGGL(k_axpy_owned<false>, grid_for(c->g.nown * nf), dim3(256), 0, c->stream, c->g, nf, a, x, y);
+}
+
+// ---- batched dot products (VecMDot + VecNorm of one FGMRES iteration in ONE pass over w) -----------
+// Each wave owns a chunk of owned entries (CHUNK per lane kept in registers), loops over the k basis
+// vectors and reduces with DPP shuffles; per-wave partials go to gs_partial[i][wave], a second tiny
+// kernel sums them in a fixed order (deterministic).  The k-th extra output is <w2, w2>.
+constexpr int MD_CHUNK = 4;
+
+__device__ __forceinline__ double wave_sum(double v) {
+#pragma unroll
+    for (int o = 32; o > 0; o >>= 1) v += __shfl_down(v, o, 64);
+    return v;
+}
+
+__global__ __launch_bounds__(256) void k_multi_dot(GridDev g, int nf, const double *V, long vstride, int k,
+                                                   const double *w, const double *w2, double *partial,
+                                                   long nwaves) {
+    const long wave = ((long)blockIdx.x * blockDim.x + threadIdx.x) >> 6;
+    const int lane = threadIdx.x & 63;
+    if (wave >= nwaves) return;
+    const long nall = g.nown * nf;
+    long idx[MD_CHUNK];
+    double wv[MD_CHUNK];
+    bool ok[MD_CHUNK];
+#pragma unroll
+    for (int j = 0; j < MD_CHUNK; ++j) {
+        const long t = (wave * MD_CHUNK + j) * 64 + lane;
+        ok[j] = t < nall;
+        const long tt = ok[j] ? t : 0;
+        const long f = tt / g.nown, i = tt - f * g.nown;
+        idx[j] = f * g.ntot + g.np + i;
+        wv[j] = ok[j] ? w[idx[j]] : 0.0;
+    }
+    for (int i = 0; i < k; ++i) {
+        const double *Vi = V + (long)i * vstride;
+        double s = 0.0;
+#pragma unroll
+        for (int j = 0; j < MD_CHUNK; ++j) s += ok[j] ? Vi[idx[j]] * wv[j] : 0.0;
+        s = wave_sum(s);
+        if (lane == 0) partial[(long)i * nwaves + wave] = s;
+    }
+    if (w2) {
+        double s = 0.0;
+#pragma unroll
+        for (int j = 0; j < MD_CHUNK; ++j) {
+            const double t = ok[j] ? w2[idx[j]] : 0.0;
+            s += t * t;
+        }
+        s = wave_sum(s);
+        if (lane == 0) partial[(long)k * nwaves + wave] = s;
+    }
+}
+
+__global__ __launch_bounds__(256) void k_reduce_partials(const double *partial, long nwaves, double *out) {
+    __shared__ double sh[4];
+    const double *p = partial + (long)blockIdx.x * nwaves;
+    double s = 0.0;
+    for (long i = threadIdx.x; i < nwaves; i += 256) s += p[i];
+    s = wave_sum(s);
+    if ((threadIdx.x & 63) == 0) sh[threadIdx.x >> 6] = s;
+    __syncthreads();
+    if (threadIdx.x == 0) out[blockIdx.x] = sh[0] + sh[1] + sh[2] + sh[3];
+}
+
+static long md_nwaves(const tp_ctx *c, int nf) {
+    const long nall = c->g.nown * nf;
+    return (nall + 64L * MD_CHUNK - 1) / (64L * MD_CHUNK);
+}
+
+void multi_dot(tp_ctx *c, int nf, const double *V, long vstride, int k, const double *w, const double *w2,
+               double *host_out) {
+    const long nw = md_nwaves(c, nf);
+    const int nout = k + (w2 ? 1 : 0);
+    if ((long)c->gs_partial.n < (long)nout * nw) c->gs_partial.alloc((size_t)(nout + 32) * nw);
+    if ((long)c->red_out.n < nout) c->red_out.alloc(nout + 64);
+    hipLaunchKernelGGL(k_multi_dot, grid_for(nw * 64), dim3(256), 0, c->stream, c->g, nf, V, vstride, k, w, w2,
+                       c->gs_partial.p, nw);
+    hipLaunchKernelGGL(k_reduce_partials, dim3(nout), dim3(256), 0, c->stream, c->gs_partial.p, nw, c->red_out.p);
+    TP_HIP(hipGetLastError());
+    allreduce_sum(c, c->red_out.p, nout);
+    TP_HIP(hipMemcpyAsync(host_out, c->red_out.p, sizeof(double) * nout, hipMemcpyDeviceToHost, c->stream));
+    TP_HIP(hipStreamSynchronize(c->stream));
+}
+
+double norm2(tp_ctx *c, int nf, const double *x) {
+    double s = 0.0;
+    multi_dot(c, nf, x, 0, 0, x, x, &s);
+    return sqrt(s);
+}
+
+// w += sign * sum_i h_i V_i  (VecMAXPY): one pass over w, k coalesced streams
+__global__ __launch_bounds__(256) void k_multi_axpy(GridDev g, int nf, const double *V, long vstride, int k,
+                                                    const double *h, double sign, double *w) {
+    const long t = (long)blockIdx.x * blockDim.x + threadIdx.x;
+    if (t >= g.nown * nf) return;
+    const long f = t / g.nown, i = t - f * g.nown;
+    const long c = f * g.ntot + g.np + i;
+    double s = 0.0;
+    for (int j = 0; j < k; ++j) s += h[j] * V[(long)j * vstride + c];
+    w[c] += sign * s;
+}
+
+void multi_axpy(tp_ctx *c, int nf, const double *V, long vstride, int k, const double *hcoef_host, double sign,
+                double *w) {
+    if (k <= 0) return;
+    if ((int)c->gs_h.n < k) c->gs_h.alloc(k + 64);
+    TP_HIP(hipMemcpyAsync(c->gs_h.p, hcoef_host, sizeof(double) * k, hipMemcpyHostToDevice, c->stream));
+    hipLaunchKernelGGL(k_multi_axpy, grid_for(c->g.nown * nf), dim3(256), 0, c->stream, c->g, nf, V, vstride, k,
+                       c->gs_h.p, sign, w);
+    TP_HIP(hipGetLastError());
+    // the host buffer may be reused by the caller right away
+    TP_HIP(hipStreamSynchronize(c->stream));
+}
+
+// ---- block stencil mat-vec: y = J x  (MatMult) ----------------------------------------------------
+// MODE 0: y = J x ; MODE 1: r = x0 - J[:, :NC] y   (stage-1 output has zero secondary fields)
+template <int B, int NS, int NC, int MODE>
+__global__ __launch_bounds__(256) void k_spmv_block(GridDev g, const double *__restrict__ J,
+                                                    const double *__restrict__ x, const double *__restrict__ x0,
+                                                    double *__restrict__ y) {
+    const long tid = (long)blockIdx.x * blockDim.x + threadIdx.x;
+    if (tid >= g.nown) return;
+    const long c = g.np + tid, nt = g.ntot;
+    const long off[7] = {0, -1, 1, -(long)g.n0, (long)g.n0, -g.np, g.np};
+    double acc[B];
+#pragma unroll
+    for (int r = 0; r < B; ++r) acc[r] = 0.0;
+#pragma unroll
+    for (int s = 0; s < NS; ++s) {
+        double xv[NC];
+#pragma unroll
+        for (int k = 0; k < NC; ++k) xv[k] = x[(long)k * nt + c + off[s]];
+#pragma unroll
+        for (int r = 0; r < B; ++r)
+#pragma unroll
+            for (int k = 0; k < NC; ++k) acc[r] += J[((long)(s * B + r) * B + k) * nt + c] * xv[k];
+    }
+#pragma unroll
+    for (int r = 0; r < B; ++r) y[(long)r * nt + c] = MODE ? x0[(long)r * nt + c] - acc[r] : acc[r];
+}
+
+void spmv_block(tp_ctx *c, const double *J, const double *x, double *y) {
+    const GridDev &g = c->g;
+    const dim3 gr = grid_for(g.nown), bl(256);
+    const bool d3 = g.gn2 > 1;
+    if (c->b == 3) {
+        if (d3) hipLaunchKernelGGL((k_spmv_block<3, 7, 3, 0>), gr, bl, 0, c->stream, g, J, x, x, y);
+        else    hipLaunchKernelGGL((k_spmv_block<3, 5, 3, 0>), gr, bl, 0, c->stream, g, J, x, x, y);
+    } else {
+        if (d3) hipLaunchKernelGGL((k_spmv_block<2, 7, 2, 0>), gr, bl, 0, c->stream, g, J, x, x, y);
+        else    hipLaunchKernelGGL((k_spmv_block<2, 5, 2, 0>), gr, bl, 0, c->stream, g, J, x, x, y);
+    }
+    TP_HIP(hipGetLastError());
+}
+
+void resid_block_cols(tp_ctx *c, const double *J, const double *x, const double *y, int ncols, double *r) {
+    const GridDev &g = c->g;
+    const dim3 gr = grid_for(g.nown), bl(256);
+    const bool d3 = g.gn2 > 1;
+#define RL(B, NS, NC) hipLaunchKernelGGL((k_spmv_block<B, NS, NC, 1>), gr, bl, 0, c->stream, g, J, y, x, r)
+    if (c->b == 3) {
+        if (ncols == 1) { if (d3) RL(3, 7, 1); else RL(3, 5, 1); }
+        else if (ncols == 2) { if (d3) RL(3, 7, 2); else RL(3, 5, 2); }
+        else { if (d3) RL(3, 7, 3); else RL(3, 5, 3); }
+    } else {
+        if (ncols == 1) { if (d3) RL(2, 7, 1); else RL(2, 5, 1); }
+        else { if (d3) RL(2, 7, 2); else RL(2, 5, 2); }
+    }
+#undef RL
+    TP_HIP(hipGetLastError());
+}
+
+// ---- scalar stencil: y = z + alpha * A x ----------------------------------------------------------
+__global__ __launch_bounds__(256) void k_spmv_scalar(GridDev g, Stencil A, const double *__restrict__ x,
+                                                     double *__restrict__ y, double alpha,
+                                                     const double *__restrict__ z) {
+    const long tid = (long)blockIdx.x * blockDim.x + threadIdx.x;
+    if (tid >= g.nown) return;
+    const long c = g.np + tid;
+    const long off[7] = {0, -1, 1, -(long)g.n0, (long)g.n0, -g.np, g.np};
+    double s = 0.0;
+#pragma unroll
+    for (int k = 0; k < 7; ++k) s += A.slot(k)[c] * x[c + off[k]];
+    y[c] = (z ? z[c] : 0.0) + alpha * s;
+}
+
+void spmv_scalar(tp_ctx *c, const GridDev &g, const Stencil &A, const double *x, double *y, double alpha,
+                 const double *z) {
+    hipLaunchKernelGGL(k_spmv_scalar, grid_for(g.nown), dim3(256), 0, c->stream, g, A, x, y, alpha, z);
+    TP_HIP(hipGetLastError());
+}
+
+// ---- Quasi-/True-IMPES decoupling (preconditioners.py:684-711,785-808,1445-1543) -------------------
+// At[slot][i][j] = J[slot][q_i][q_j] - d_i * J[slot][s][q_j],  d_i = D_{q_i s} / D_ss per cell,
+// D = diagonal entries (QI) or column sums (TI).  A per-cell row operation: no SpGEMM.
+template <int B>
+__global__ void k_decoup_coef(GridDev g, const double *J, int npri, int ti, double *d) {
+    const long tid = (long)blockIdx.x * blockDim.x + threadIdx.x;
+    if (tid >= g.nown) return;
+    const long c = g.np + tid, nt = g.ntot;
+    const int s = B - 1;
+    const long off[7] = {0, -1, 1, -(long)g.n0, (long)g.n0, -g.np, g.np};
+    auto colsum = [&](int q) {
+        // sum over rows i of block(q,s)[i, j=c]: diag at c, slot(+a) of the row below, slot(-a) of the row above
+        double v = J[((long)(0 * B + q) * B + s) * nt + c];
+        if (ti) {
+#pragma unroll
+            for (int a = 0; a < 3; ++a) {
+                v += J[((long)((2 + 2 * a) * B + q) * B + s) * nt + c + off[1 + 2 * a]];   // row c-a, slot +a
+                v += J[((long)((1 + 2 * a) * B + q) * B + s) * nt + c + off[2 + 2 * a]];   // row c+a, slot -a
+            }
+        }
+        return v;
+    };
+    const double dss = colsum(s);
+    for (int i = 0; i < npri; ++i) d[(long)i * nt + c] = colsum(i) / dss;
+}
+
+template <int B>
+__global__ void k_decoup_apply(GridDev g, const double *J, int npri, const double *d, double *At) {
+    const long tid = (long)blockIdx.x * blockDim.x + threadIdx.x;
+    if (tid >= g.nown) return;
+    const long c = g.np + tid, nt = g.ntot;
+    const int s = B - 1;
+    for (int slot = 0; slot < 7; ++slot)
+        for (int i = 0; i < npri; ++i) {
+            const double di = d[(long)i * nt + c];
+            for (int j = 0; j < npri; ++j)
+                At[((long)(slot * npri + i) * npri + j) * nt + c] =
+                    J[((long)(slot * B + i) * B + j) * nt + c] - di * J[((long)(slot * B + s) * B + j) * nt + c];
+        }
+}
+
+void decouple(tp_ctx *c) {
+    const GridDev &g = c->g;
+    const int npri = c->opt.pc_kind == 1 ? 2 : 1;
+    const long nt = g.ntot;
+    const int B = c->b;
+    if (c->opt.decoup == 0) {
+        // "No": Atilde is the primary block of J itself -- zero-copy views of the J planes
+        c->opA00.base = c->J.p;                                  c->opA00.slot_stride = (long)B * B * nt;
+        c->opA01.base = c->J.p + 1 * nt;                         c->opA01.slot_stride = (long)B * B * nt;
+        c->opA10.base = c->J.p + (long)B * nt;                   c->opA10.slot_stride = (long)B * B * nt;
+        return;
+    }
+    if (c->At.n < (size_t)7 * npri * npri * nt) c->At.alloc((size_t)7 * npri * npri * nt);
+    if (c->dcoef.n < (size_t)npri * nt) c->dcoef.alloc((size_t)npri * nt);
+    const int ti = c->opt.decoup == 2;
+    if (ti && c->comm) halo_exchange(c, g, c->J.p, 7 * B * B, nt);   // column sums read neighbour rows
+    const dim3 gr = grid_for(g.nown), bl(256);
+    if (B == 3) {
+        hipLaunchKernelGGL(k_decoup_coef<3>, gr, bl, 0, c->stream, g, c->J.p, npri, ti, c->dcoef.p);
+        hipLaunchKernelGGL(k_decoup_apply<3>, gr, bl, 0, c->stream, g, c->J.p, npri, c->dcoef.p, c->At.p);
+    } else {
+        hipLaunchKernelGGL(k_decoup_coef<2>, gr, bl, 0, c->stream, g, c->J.p, npri, ti, c->dcoef.p);
+        hipLaunchKernelGGL(k_decoup_apply<2>, gr, bl, 0, c->stream, g, c->J.p, npri, c->dcoef.p, c->At.p);
+    }
+    TP_HIP(hipGetLastError());
+    const long ss = (long)npri * npri * nt;
+    c->opA00.base = c->At.p;            c->opA00.slot_stride = ss;
+    c->opA01.base = c->At.p + nt;       c->opA01.slot_stride = ss;
+    c->opA10.base = c->At.p + 2 * nt;   c->opA10.slot_stride = ss;
+}
+
+// out = x_q - d_q x_s   (preconditioners.py:894-895, 1559-1560)
+__global__ void k_stage1_rhs(GridDev g, const double *x, const double *d, int q, int s, double *out) {
+    const long tid = (long)blockIdx.x * blockDim.x + threadIdx.x;
+    if (tid >= g.nown) return;
+    const long c = g.np + tid, nt = g.ntot;
+    out[c] = d ? x[(long)q * nt + c] - d[(long)q * nt + c] * x[(long)s * nt + c] : x[(long)q * nt + c];
+}
+
+void stage1_rhs(tp_ctx *c, const double *x, int q, double *out) {
+    const double *d = c->opt.decoup == 0 ? nullptr : c->dcoef.p;
+    hipLaunchKernelGGL(k_stage1_rhs, grid_for(c->g.nown), dim3(256), 0, c->stream, c->g, x, d, q, c->b - 1, out);
+    TP_HIP(hipGetLastError());
+}
+
+}  // namespace tp

@@ -1,0 +1,255 @@
+// Host orchestration of the hot path: PC set-up/apply, FGMRES, Newton.
+//
+//   pc_setup / pc_apply  = PCSetUp / PCApply of PCCOMPOSITE multiplicative("python,bjacobi")
+//                          (singlephase.py:341-351, twophase.py:531-550,582-597) with the python stage
+//                          being CPRStage1PC (preconditioners.py:335-906) or CPTRStage1PC (:1243-1571)
+//   fgmres               = KSP fgmres, right PC, restart/max_it 200, classical Gram-Schmidt without
+//                          refinement (twophase.py:426-432)
+//   newton               = SNES newtonls with Firedrake's default `basic` line search
+//                          (thermalmodel.py:36-42,165)
+// The loops live here (C++) rather than in Python so that one Krylov iteration costs kernel time,
+// not interpreter time; the Python PC classes call the same stage functions through the C ABI.
+#include "tp_common.hpp"
+#include <cmath>
+#include <algorithm>
+
+namespace tp {
+
+// ------------------------------------------------------------------------------------------------
+static void ensure_work(tp_ctx *c) {
+    const size_t nv = (size_t)c->b * c->g.ntot;
+    if (c->w1.n < nv) { c->w1.alloc(nv); c->w2.alloc(nv); c->w3.alloc(nv); c->w4.alloc(nv); }
+}
+
+void pc_setup(tp_ctx *c) {
+    TP_REQUIRE(c->jac_ready, "pc_setup needs an assembled Jacobian");
+    ensure_work(c);
+    // stage 1: decoupling + AMG hierarchies (CPRStage1PC.update / CPTRStage1PC.update)
+    decouple(c);
+    if (!c->amg_p) {
+        // coarsening schedule from mean face transmissibilities (decided once; structure is static)
+        double st[3] = {0, 0, 0};
+        const long nt = c->g.ntot;
+        std::vector<double> h(nt);
+        for (int a = 0; a < 3; ++a) {
+            TP_HIP(hipMemcpy(h.data(), c->TK[a].p, nt * sizeof(double), hipMemcpyDeviceToHost));
+            double s = 0.0;
+            long cnt = 0;
+            const int n[3] = {c->g.n0, c->g.n1, c->g.n2};
+            for (int i2 = 0; i2 < n[2]; ++i2)
+                for (int i1 = 0; i1 < n[1]; ++i1)
+                    for (int i0 = 0; i0 < n[0]; ++i0) {
+                        const int idx[3] = {i0, i1, i2};
+                        if (idx[a] >= n[a] - 1) continue;
+                        s += h[c->g.np * (i2 + 1) + (long)c->g.n0 * i1 + i0];
+                        ++cnt;
+                    }
+            st[a] = cnt ? s / cnt : 0.0;
+        }
+        amg_build(c, c->amg_p, st);
+        if (c->opt.pc_kind == 1) {
+            double sg[3];
+            for (int a = 0; a < 3; ++a) {
+                const double hh = c->grid.h[a];
+                const int n[3] = {c->g.n0, c->g.n1, c->g.n2};
+                sg[a] = n[a] > 1 ? c->vol / (hh * hh) : 0.0;
+            }
+            amg_build(c, c->amg_T, sg);
+        }
+    }
+    amg_setup(c, c->amg_p, c->opA00);
+    if (c->opt.pc_kind == 1) {
+        TP_REQUIRE(c->Sm.p, "pc_cptr needs the S~ operator (assemble with want_schur)");
+        Stencil S;
+        S.base = c->Sm.p;
+        S.slot_stride = c->g.ntot;
+        amg_setup(c, c->amg_T, S);
+    }
+    // stage 2: numeric block-ILU(0) of every tile
+    ilu_factor(c);
+    c->pc_ready = true;
+}
+
+// y = B1 x :  CPRStage1PC.apply (preconditioners.py:881-903) / CPTRStage1PC.apply (:1550-1567)
+void stage1_apply(tp_ctx *c, const double *x, double *y) {
+    const GridDev &g = c->g;
+    const long nt = g.ntot;
+    ensure_work(c);
+    double *r0 = c->w3.p, *r1 = c->w3.p + nt, *t = c->w3.p + 2 * nt;   // w3 has >= 2 planes; t only for b=3
+    // y_s = 0 for the non-primary fields (:902-903, :1566-1567)
+    const int npri = c->opt.pc_kind == 1 ? 2 : 1;
+    for (int f = npri; f < c->b; ++f) vec_zero(c, y + (long)f * nt, nt);
+    stage1_rhs(c, x, 0, r0);                       // r_p = x_p - (D_ps D_ss^-1) x_s
+    if (c->opt.pc_kind == 0) {
+        amg_vcycle(c, c->amg_p, r0, y);
+        return;
+    }
+    TP_REQUIRE(c->b == 3, "pc_cptr is a two-phase preconditioner");
+    stage1_rhs(c, x, 1, r1);
+    // PCFIELDSPLIT schur FULL on (p,T) (twophase.py:536-545): K(A00), K(S~) = one V-cycle each
+    double *y0 = y, *y1 = y + nt;
+    amg_vcycle(c, c->amg_p, r0, c->w4.p);                                   // y0 = K(A00) r0
+    spmv_scalar(c, g, c->opA10, c->w4.p, t, -1.0, r1);                      // t = r1 - A10 y0
+    amg_vcycle(c, c->amg_T, t, y1);                                         // y1 = K(S~) t
+    spmv_scalar(c, g, c->opA01, y1, t, -1.0, r0);                           // t = r0 - A01 y1
+    amg_vcycle(c, c->amg_p, t, y0);                                         // y0 = K(A00) t
+}
+
+// composite multiplicative: y = B1 x ; r = x - J y ; y += B2 r
+void pc_apply(tp_ctx *c, const double *x, double *y) {
+    TP_REQUIRE(c->pc_ready, "pc_apply before pc_setup");
+    const int npri = c->opt.pc_kind == 1 ? 2 : 1;
+    stage1_apply(c, x, y);
+    if (c->comm) halo_exchange(c, c->g, y, npri, c->g.ntot);
+    resid_block_cols(c, c->J.p, x, y, npri, c->w1.p);        // secondary fields of y are zero
+    ilu_solve(c, c->w1.p, y, y);                             // y = y + M^-1 r
+}
+
+// ------------------------------------------------------------------------------------------------
+// FGMRES(m) from x0 = 0.  Returns KSP reason (2 = CONVERGED_RTOL, 3 = CONVERGED_ATOL, -3 = DIVERGED_ITS).
+int fgmres(tp_ctx *c, const double *bvec, double *x, int *its_out, double *rnorm_out) {
+    const GridDev &g = c->g;
+    const int B = c->b;
+    const long nv = (long)B * g.ntot;
+    const int maxit = c->opt.ksp_max_it;
+    const int restart = std::max(1, std::min(c->opt.ksp_restart, maxit));
+    ensure_work(c);
+    // basis storage grows on demand (restart 200 x 2 vectors would be 10.8 GB on SPE10 3-D)
+    auto ensure_basis = [&](int need) {
+        if (c->gs_cap >= need) return;
+        int cap = std::max(need, std::min(restart + 1, std::max(32, 2 * c->gs_cap)));
+        DBuf<double> nV, nZ;
+        nV.alloc((size_t)cap * nv);
+        nZ.alloc((size_t)cap * nv);
+        if (c->gs_cap > 0) {
+            TP_HIP(hipMemcpyAsync(nV.p, c->V.p, sizeof(double) * c->gs_cap * nv, hipMemcpyDeviceToDevice, c->stream));
+            TP_HIP(hipMemcpyAsync(nZ.p, c->Z.p, sizeof(double) * c->gs_cap * nv, hipMemcpyDeviceToDevice, c->stream));
+            TP_HIP(hipStreamSynchronize(c->stream));
+        }
+        std::swap(c->V.p, nV.p); std::swap(c->V.n, nV.n);
+        std::swap(c->Z.p, nZ.p); std::swap(c->Z.n, nZ.n);
+        c->gs_cap = cap;
+    };
+    vec_zero(c, x, nv);
+    const double bnorm = norm2(c, B, bvec);
+    int its = 0;
+    if (bnorm == 0.0) { *its_out = 0; *rnorm_out = 0.0; return 2; }
+    if (!std::isfinite(bnorm)) { *its_out = 0; *rnorm_out = bnorm; return -9; }
+    const double tol = std::max(c->opt.ksp_rtol * bnorm, c->opt.ksp_atol);
+    double beta = bnorm;
+    const double *rsrc = bvec;
+    std::vector<double> H, cs, sn, gvec, hcol, yk;
+    while (true) {
+        const int m = std::min(restart, maxit - its);
+        H.assign((size_t)(m + 1) * m, 0.0);
+        cs.assign(m, 0.0); sn.assign(m, 0.0); gvec.assign(m + 1, 0.0);
+        hcol.resize(m + 2);
+        gvec[0] = beta;
+        ensure_basis(2);
+        vec_scale_to(c, B, 1.0 / beta, rsrc, c->V.p);                      // v0 = r/beta
+        if (c->comm) halo_exchange(c, g, c->V.p, B, g.ntot);
+        int k = 0, reason = 0;
+        double res = beta;
+        for (int j = 0; j < m; ++j) {
+            ensure_basis(j + 2);
+            double *vj = c->V.p + (long)j * nv, *zj = c->Z.p + (long)j * nv, *w = c->V.p + (long)(j + 1) * nv;
+            pc_apply(c, vj, zj);                                            // z_j = M^-1 v_j
+            if (c->comm) halo_exchange(c, g, zj, B, g.ntot);
+            spmv_block(c, c->J.p, zj, w);                                   // w = J z_j
+            multi_dot(c, B, c->V.p, nv, j + 1, w, nullptr, hcol.data());    // h = V^T w   (VecMDot)
+            multi_axpy(c, B, c->V.p, nv, j + 1, hcol.data(), -1.0, w);      // w -= V h    (VecMAXPY)
+            const double hn = norm2(c, B, w);
+            for (int i = 0; i <= j; ++i) H[(size_t)i * m + j] = hcol[i];
+            H[(size_t)(j + 1) * m + j] = hn;
+            for (int i = 0; i < j; ++i) {                                   // previous Givens rotations
+                const double t = cs[i] * H[(size_t)i * m + j] + sn[i] * H[(size_t)(i + 1) * m + j];
+                H[(size_t)(i + 1) * m + j] = -sn[i] * H[(size_t)i * m + j] + cs[i] * H[(size_t)(i + 1) * m + j];
+                H[(size_t)i * m + j] = t;
+            }
+            const double d = std::hypot(H[(size_t)j * m + j], H[(size_t)(j + 1) * m + j]);
+            cs[j] = H[(size_t)j * m + j] / d;
+            sn[j] = H[(size_t)(j + 1) * m + j] / d;
+            H[(size_t)j * m + j] = d;
+            H[(size_t)(j + 1) * m + j] = 0.0;
+            gvec[j + 1] = -sn[j] * gvec[j];
+            gvec[j] = cs[j] * gvec[j];
+            ++its;
+            k = j + 1;
+            res = std::fabs(gvec[j + 1]);
+            if (!std::isfinite(res)) { reason = -9; break; }               // KSP_DIVERGED_NANORINF
+            if (res <= tol) { reason = 2; break; }
+            if (hn == 0.0) { reason = 2; break; }
+            vec_scale_to(c, B, 1.0 / hn, w, w);                             // v_{j+1} = w/||w||
+            if (c->comm) halo_exchange(c, g, w, B, g.ntot);
+        }
+        // y = H^-1 g ; x += Z y
+        yk.assign(k, 0.0);
+        for (int i = k - 1; i >= 0; --i) {
+            double s = gvec[i];
+            for (int q = i + 1; q < k; ++q) s -= H[(size_t)i * m + q] * yk[q];
+            yk[i] = s / H[(size_t)i * m + i];
+        }
+        multi_axpy(c, B, c->Z.p, nv, k, yk.data(), 1.0, x);
+        if (reason) { *its_out = its; *rnorm_out = res; return reason; }
+        if (its >= maxit) { *its_out = its; *rnorm_out = res; return -3; }
+        // restart: r = b - J x
+        if (c->comm) halo_exchange(c, g, x, B, g.ntot);
+        resid_block_cols(c, c->J.p, bvec, x, B, c->w2.p);
+        beta = norm2(c, B, c->w2.p);
+        rsrc = c->w2.p;
+        if (beta <= tol) { *its_out = its; *rnorm_out = beta; return 2; }
+    }
+}
+
+// ------------------------------------------------------------------------------------------------
+void newton(tp_ctx *c, tp_solve_info *info) {
+    const GridDev &g = c->g;
+    const int B = c->b;
+    const long nv = (long)B * g.ntot;
+    ensure_work(c);
+    const bool schur = c->opt.pc_kind == 1;
+    if (schur && c->Sm.n < (size_t)7 * g.ntot) c->Sm.alloc((size_t)7 * g.ntot);
+    TP_REQUIRE(c->u.n > 0, "state not set");
+    tp::DBuf<double> *dx = &c->dx;
+    if (dx->n < (size_t)nv) dx->alloc(nv);
+
+    if (c->comm) halo_exchange(c, g, c->u.p, B, g.ntot);
+    assemble(c, true, schur);
+    double fnorm = norm2(c, B, c->R.p);
+    const double fnorm0 = fnorm;
+    int nits = 0, lits = 0, reason = 0, kreason = 0;
+    if (!std::isfinite(fnorm)) reason = -4;                      // SNES_DIVERGED_FNORM_NAN
+    else if (fnorm < c->opt.snes_atol) reason = 2;               // SNES_CONVERGED_FNORM_ABS
+    while (reason == 0) {
+        if (nits >= c->opt.snes_max_it) { reason = -5; break; }  // SNES_DIVERGED_MAX_IT
+        pc_setup(c);
+        int kits = 0;
+        double rn = 0.0;
+        kreason = fgmres(c, c->R.p, dx->p, &kits, &rn);
+        lits += kits;
+        if (kreason < 0) { reason = -3; break; }                 // SNES_DIVERGED_LINEAR_SOLVE
+        vec_axpy_owned(c, B, -1.0, dx->p, c->u.p);               // basic line search, lambda = 1
+        if (c->comm) halo_exchange(c, g, c->u.p, B, g.ntot);
+        assemble(c, true, schur);
+        ++nits;
+        double nrm[3];
+        multi_dot(c, B, c->R.p, 0, 0, c->R.p, c->R.p, &nrm[0]);
+        multi_dot(c, B, dx->p, 0, 0, dx->p, dx->p, &nrm[1]);
+        multi_dot(c, B, c->u.p, 0, 0, c->u.p, c->u.p, &nrm[2]);
+        fnorm = std::sqrt(nrm[0]);
+        const double snorm = std::sqrt(nrm[1]), xnorm = std::sqrt(nrm[2]);
+        if (!std::isfinite(fnorm)) reason = -4;
+        else if (fnorm < c->opt.snes_atol) reason = 2;
+        else if (fnorm <= c->opt.snes_rtol * fnorm0) reason = 3;  // SNES_CONVERGED_FNORM_RELATIVE
+        else if (snorm < c->opt.snes_stol * xnorm) reason = 4;    // SNES_CONVERGED_SNORM_RELATIVE
+    }
+    info->nits = nits;
+    info->lits = lits;
+    info->reason = reason;
+    info->last_ksp_reason = kreason;
+    info->fnorm0 = fnorm0;
+    info->fnorm = fnorm;
+    info->vcycles = (int)c->vcycles;
+}
+
+}  // namespace tp

@@ -1,0 +1,330 @@
+"""ctypes binding of libthermalporous_hip.so -- the compute engine behind SinglePhase/TwoPhase.solve().
+
+This is the FFI stub a maintainer of the reference would add: the reference reaches
+its native hot path through petsc4py/Firedrake at ``self.solver.solve()``
+(/root/reference/thermalporous/thermalmodel.py:165); here the same call lands in ``tp_newton_solve``.
+There is NO CPU fallback: without the HIP library or without a GPU the engine raises.
+
+Slab layout: each rank owns planes [off2, off2+n2) along internal axis 2 and stores every cell array
+with one halo plane per side (include/thermalporous_hip.h).
+"""
+import ctypes as C
+import os
+
+import numpy as np
+
+_LIB = None
+_LIBPATH = os.path.join(os.path.dirname(os.path.abspath(__file__)), "libthermalporous_hip.so")
+
+
+class EngineError(RuntimeError):
+    pass
+
+
+class tp_grid(C.Structure):
+    _fields_ = [("n0", C.c_int32), ("n1", C.c_int32), ("n2", C.c_int32), ("gn2", C.c_int32), ("off2", C.c_int32),
+                ("h", C.c_double*3), ("gaxis", C.c_int32), ("nphase", C.c_int32), ("rank", C.c_int32),
+                ("nranks", C.c_int32)]
+
+
+class tp_params(C.Structure):
+    _names = ("ko", "kw", "kr", "c_v_w", "c_v_o", "c_r", "rho_r", "p_inj", "p_prod", "T_inj", "T_prod", "API",
+              "p_ref", "g", "S_o", "U", "rate")
+    _fields_ = [(k, C.c_double) for k in _names]
+
+
+class tp_source(C.Structure):
+    _fields_ = [("cell", C.c_int64), ("kind", C.c_int32), ("constant_rate", C.c_int32), ("wt", C.c_double),
+                ("bhp", C.c_double), ("max_rate", C.c_double), ("WI", C.c_double)]
+
+
+class tp_options(C.Structure):
+    _fields_ = [("pc_kind", C.c_int32), ("decoup", C.c_int32), ("ksp_rtol", C.c_double), ("ksp_atol", C.c_double),
+                ("ksp_max_it", C.c_int32), ("ksp_restart", C.c_int32), ("snes_rtol", C.c_double),
+                ("snes_atol", C.c_double), ("snes_stol", C.c_double), ("snes_max_it", C.c_int32),
+                ("amg_omega", C.c_double), ("amg_nu", C.c_int32), ("amg_min_cells", C.c_int32),
+                ("ilu_t1", C.c_int32), ("ilu_t2", C.c_int32)]
+
+
+class tp_solve_info(C.Structure):
+    _fields_ = [("nits", C.c_int32), ("lits", C.c_int32), ("reason", C.c_int32), ("last_ksp_reason", C.c_int32),
+                ("fnorm0", C.c_double), ("fnorm", C.c_double), ("vcycles", C.c_int32)]
+
+
+# every symbol include/thermalporous_hip.h declares (tests check that the library exports them all)
+API_SYMBOLS = (
+    "tp_last_error", "tp_version", "tp_create", "tp_destroy", "tp_set_options", "tp_comm_unique_id", "tp_comm_init",
+    "tp_set_field", "tp_finalize_fields", "tp_set_sources", "tp_set_state", "tp_get_state", "tp_set_old_state",
+    "tp_set_dt", "tp_residual", "tp_jacobian", "tp_get_residual", "tp_export_jacobian", "tp_export_schur",
+    "tp_well_rates", "tp_vec_create", "tp_vec_set", "tp_vec_get", "tp_vec_copy_residual", "tp_spmv", "tp_pc_setup",
+    "tp_pc_apply", "tp_stage1_update", "tp_stage1_apply", "tp_ilu0_factor", "tp_ilu0_solve", "tp_amg_setup",
+    "tp_amg_vcycle", "tp_schur_apply", "tp_fgmres", "tp_newton_solve", "tp_time_kernel", "tp_amg_info",
+)
+
+DEFAULT_OPTS = dict(
+    pc="cpr", decoup="No",
+    ksp_rtol=1e-7, ksp_atol=1e-50, ksp_max_it=200, ksp_restart=200,
+    snes_rtol=1e-8, snes_atol=1e-50, snes_stol=1e-8, snes_max_it=15,
+    amg_omega=0.8, amg_min_cells=64, amg_nu=2,
+    ilu_tile=(1 << 30, 8, 8),
+)
+
+_PC = {"cpr": 0, "cptr": 1}
+_DECOUP = {"No": 0, "QI": 1, "TI": 2}
+
+
+def load_library(path=None):
+    """dlopen the in-tree HIP library; fail loudly if it has not been built (no fallback)."""
+    global _LIB
+    if _LIB is not None and path is None:
+        return _LIB
+    p = path or _LIBPATH
+    if not os.path.exists(p):
+        raise EngineError("libthermalporous_hip.so not found at %s -- run `python -c 'import __graft_entry__ as g; "
+                          "g.build()'` (hipcc --offload-arch=gfx950); there is no CPU fallback" % p)
+    lib = C.CDLL(p)
+    lib.tp_last_error.restype = C.c_char_p
+    for name in API_SYMBOLS:
+        fn = getattr(lib, name)          # AttributeError if a declared symbol is missing
+        if name != "tp_last_error":
+            fn.restype = C.c_int
+    if path is None:
+        _LIB = lib
+    return lib
+
+
+def _dptr(a):
+    return a.ctypes.data_as(C.POINTER(C.c_double))
+
+
+def slab_range(gn2, rank, nranks):
+    """Planes [lo, hi) of internal axis 2 owned by `rank` (as even as possible, low ranks get the extras)."""
+    base, rem = divmod(gn2, nranks)
+    lo = rank*base + min(rank, rem)
+    return lo, lo + base + (1 if rank < rem else 0)
+
+
+class HipEngine:
+    """Same interface as oracle.engine.OracleEngine; all arithmetic on the GPU."""
+
+    def __init__(self, spec, opts=None, rank=0, nranks=1, device=None, comm_bootstrap=None):
+        self.lib = load_library()
+        self.spec = spec
+        self.opts = dict(DEFAULT_OPTS)
+        self.opts.update(opts or {})
+        self.nph = int(spec["nphase"])
+        self.b = self.nph + 1
+        n0, n1, gn2 = (int(v) for v in spec["n"])
+        self.rank, self.nranks = int(rank), int(nranks)
+        if self.nranks > 1 and gn2 < self.nranks:
+            raise EngineError("more slabs than planes along the slab axis")
+        self.lo, self.hi = slab_range(gn2, self.rank, self.nranks)
+        self.n = (n0, n1, self.hi - self.lo)
+        self.gn = (n0, n1, gn2)
+        self.np_ = n0*n1
+        self.ntot = self.np_*(self.n[2] + 2)
+        g = tp_grid(n0, n1, self.n[2], gn2, self.lo, (C.c_double*3)(*[float(h) for h in spec["h"]]),
+                    int(spec["gaxis"]), self.nph, self.rank, self.nranks)
+        prm = tp_params(*[float(spec["prm"][k]) for k in tp_params._names])
+        self._opt = self._make_options(self.opts)
+        self.ctx = C.c_void_p()
+        if device is None:
+            device = int(os.environ.get("LOCAL_RANK", "0")) if self.nranks > 1 else 0
+        self._ck(self.lib.tp_create(C.byref(g), C.byref(prm), C.byref(self._opt), int(device), C.byref(self.ctx)))
+        if self.nranks > 1:
+            if comm_bootstrap is None:
+                raise EngineError("multi-slab engine needs comm_bootstrap(make_id) -> 128-byte id")
+            ident = comm_bootstrap(self._unique_id)
+            self._ck(self.lib.tp_comm_init(self.ctx, C.c_char_p(bytes(ident))))
+        # fields (slab + halo planes; halo of a physical boundary replicates the boundary plane)
+        for name, arr in (("phi", spec["phi"]), ("kT", spec["kT"]), ("K0", spec["K"][0]), ("K1", spec["K"][1]),
+                          ("K2", spec["K"][2])):
+            a = self._with_halo(np.asarray(arr, dtype=float))
+            self._ck(self.lib.tp_set_field(self.ctx, name.encode(), _dptr(a), C.c_int64(a.size)))
+        self._ck(self.lib.tp_finalize_fields(self.ctx))
+        self._set_sources(spec.get("sources"))
+        self.last = {}
+        self._vec_ids = {}
+
+    # ---- plumbing ---------------------------------------------------------------------------------
+    def _ck(self, rc):
+        if rc != 0:
+            raise EngineError(self.lib.tp_last_error().decode())
+
+    def _unique_id(self):
+        buf = C.create_string_buffer(128)
+        self._ck(self.lib.tp_comm_unique_id(buf))
+        return buf.raw
+
+    @staticmethod
+    def _make_options(o):
+        t = o["ilu_tile"]
+        return tp_options(_PC[o["pc"]], _DECOUP[o["decoup"]], o["ksp_rtol"], o["ksp_atol"], o["ksp_max_it"],
+                          o["ksp_restart"], o["snes_rtol"], o["snes_atol"], o["snes_stol"], o["snes_max_it"],
+                          o["amg_omega"], o["amg_nu"], o["amg_min_cells"], int(min(t[1], 64)), int(min(t[2], 64)))
+
+    def set_options(self, **kw):
+        self.opts.update(kw)
+        self._opt = self._make_options(self.opts)
+        self._ck(self.lib.tp_set_options(self.ctx, C.byref(self._opt)))
+
+    def _with_halo(self, a):
+        """Global internal array (gn2, n1, n0) -> this slab with halo planes, flat, C-contiguous."""
+        a = a.reshape(self.gn[2], self.gn[1], self.gn[0])
+        lo, hi = self.lo, self.hi
+        idx = np.clip(np.arange(lo - 1, hi + 1), 0, self.gn[2] - 1)
+        return np.ascontiguousarray(a[idx]).reshape(-1)
+
+    def _fields_with_halo(self, u):
+        u = np.asarray(u, dtype=float).reshape(self.b, self.gn[2], self.gn[1], self.gn[0])
+        return np.ascontiguousarray(np.stack([self._with_halo(u[f]) for f in range(self.b)])).reshape(-1)
+
+    def _strip_halo(self, flat, nf):
+        a = np.asarray(flat).reshape(nf, self.n[2] + 2, self.n[1], self.n[0])
+        return a[:, 1:-1]
+
+    def _set_sources(self, src):
+        if not src or len(src["cell"]) == 0:
+            self._ck(self.lib.tp_set_sources(self.ctx, 0, None))
+            self.src_index = np.zeros(0, dtype=int)
+            return
+        cells = np.asarray(src["cell"], dtype=np.int64)
+        plane = cells // self.np_
+        mine = np.nonzero((plane >= self.lo) & (plane < self.hi))[0]
+        self.src_index = mine                      # positions (in the global entry list) of my entries
+        arr = (tp_source*max(1, len(mine)))()
+        for k, i in enumerate(mine):
+            local = int(cells[i] - self.lo*self.np_ + self.np_)
+            arr[k] = tp_source(local, int(src["kind"][i]), int(src["const"][i]), float(src["wt"][i]),
+                               float(src["bhp"][i]), float(src["max_rate"][i]), float(src["WI"][i]))
+        self._ck(self.lib.tp_set_sources(self.ctx, len(mine), arr))
+        # the library sorts entries by cell (stable): reproduce the permutation for rate read-back
+        self._src_order = np.argsort(cells[mine], kind="stable")
+
+    # ---- engine interface ---------------------------------------------------------------------------
+    def set_state(self, u):
+        a = self._fields_with_halo(u)
+        self._ck(self.lib.tp_set_state(self.ctx, _dptr(a)))
+
+    def get_state(self):
+        """This rank's owned part of the state, shape (b, n2_local, n1, n0)."""
+        out = np.empty(self.b*self.ntot)
+        self._ck(self.lib.tp_get_state(self.ctx, _dptr(out)))
+        return self._strip_halo(out, self.b).copy()
+
+    def set_old(self, u=None):
+        if u is None:
+            self._ck(self.lib.tp_set_old_state(self.ctx, None))
+        else:
+            a = self._fields_with_halo(u)
+            self._ck(self.lib.tp_set_old_state(self.ctx, _dptr(a)))
+
+    def set_dt(self, dt):
+        self._ck(self.lib.tp_set_dt(self.ctx, C.c_double(float(dt))))
+
+    def residual(self, u=None):
+        if u is not None:
+            self.set_state(u)
+        nrm = C.c_double()
+        self._ck(self.lib.tp_residual(self.ctx, C.byref(nrm)))
+        out = np.empty(self.b*self.ntot)
+        self._ck(self.lib.tp_get_residual(self.ctx, _dptr(out)))
+        self.last_fnorm = nrm.value
+        return self._strip_halo(out, self.b).copy()
+
+    def jacobian(self, u=None, want_schur=False):
+        if u is not None:
+            self.set_state(u)
+        if want_schur and self.opts["pc"] != "cptr":
+            raise EngineError("S~ is assembled only for pc='cptr'")
+        self._ck(self.lib.tp_jacobian(self.ctx))
+        b = self.b
+        out = np.empty(7*b*b*self.ntot)
+        self._ck(self.lib.tp_export_jacobian(self.ctx, _dptr(out)))
+        J = self._strip_halo(out, 7*b*b).reshape(7, b, b, self.n[2], self.n[1], self.n[0]).copy()
+        if want_schur:
+            s = np.empty(7*self.ntot)
+            self._ck(self.lib.tp_export_schur(self.ctx, _dptr(s)))
+            return J, self._strip_halo(s, 7).copy()
+        return J
+
+    def well_rates(self):
+        n = len(self.src_index)
+        if n == 0:
+            return {}
+        r, w, o = (np.zeros(n) for _ in range(3))
+        self._ck(self.lib.tp_well_rates(self.ctx, _dptr(r), _dptr(w), _dptr(o)))
+        inv = np.empty(n, dtype=int)
+        inv[self._src_order] = np.arange(n)
+        return {"rate": r[inv], "water_rate": w[inv], "oil_rate": o[inv]}
+
+    # device vectors for the PC plug-in API / tests
+    def vec(self, name):
+        if name not in self._vec_ids:
+            i = C.c_int32()
+            self._ck(self.lib.tp_vec_create(self.ctx, C.byref(i)))
+            self._vec_ids[name] = i.value
+        return self._vec_ids[name]
+
+    def vec_set(self, name, x):
+        a = self._fields_with_halo(x)
+        self._ck(self.lib.tp_vec_set(self.ctx, self.vec(name), _dptr(a)))
+
+    def vec_get(self, name):
+        out = np.empty(self.b*self.ntot)
+        self._ck(self.lib.tp_vec_get(self.ctx, self.vec(name), _dptr(out)))
+        return self._strip_halo(out, self.b).copy()
+
+    def spmv(self, x, y):
+        self._ck(self.lib.tp_spmv(self.ctx, self.vec(x), self.vec(y)))
+
+    def pc_setup(self):
+        self._ck(self.lib.tp_pc_setup(self.ctx))
+
+    def pc_apply(self, x, y):
+        self._ck(self.lib.tp_pc_apply(self.ctx, self.vec(x), self.vec(y)))
+
+    def stage1_apply(self, x, y):
+        self._ck(self.lib.tp_stage1_apply(self.ctx, self.vec(x), self.vec(y)))
+
+    def ilu_solve(self, x, y):
+        self._ck(self.lib.tp_ilu0_solve(self.ctx, self.vec(x), self.vec(y)))
+
+    def amg_vcycle(self, which, b, fb, x, fx):
+        self._ck(self.lib.tp_amg_vcycle(self.ctx, which, fb, self.vec(b), fx, self.vec(x)))
+
+    def fgmres(self, b, x):
+        its, reason, rn = C.c_int32(), C.c_int32(), C.c_double()
+        self._ck(self.lib.tp_fgmres(self.ctx, self.vec(b), self.vec(x), C.byref(its), C.byref(reason), C.byref(rn)))
+        return its.value, reason.value, rn.value
+
+    def copy_residual_to(self, name):
+        self._ck(self.lib.tp_vec_copy_residual(self.ctx, self.vec(name)))
+
+    def time_kernel(self, which, reps):
+        ms = C.c_double()
+        self._ck(self.lib.tp_time_kernel(self.ctx, which, reps, C.byref(ms)))
+        return ms.value
+
+    def amg_info(self, which=0):
+        nl, oc = C.c_int32(), C.c_double()
+        self._ck(self.lib.tp_amg_info(self.ctx, which, C.byref(nl), C.byref(oc)))
+        return nl.value, oc.value
+
+    def newton_solve(self):
+        info = tp_solve_info()
+        self._ck(self.lib.tp_newton_solve(self.ctx, C.byref(info)))
+        self.last = dict(nits=info.nits, lits=info.lits, reason=info.reason, fnorm=info.fnorm, fnorm0=info.fnorm0,
+                         ksp_reason=info.last_ksp_reason, vcycles=info.vcycles)
+        return self.last
+
+    def close(self):
+        if self.ctx:
+            self.lib.tp_destroy(self.ctx)
+            self.ctx = C.c_void_p()
+
+    def __del__(self):
+        try:
+            self.close()
+        except Exception:
+            pass
