@@ -109,6 +109,12 @@ int tp_set_state(tp_ctx *ctx, const double *u_host);      /* b*ntot doubles */
 int tp_get_state(tp_ctx *ctx, double *u_host);
 int tp_set_old_state(tp_ctx *ctx, const double *u_host);  /* NULL: u_ <- u */
 int tp_set_dt(tp_ctx *ctx, double dt);
+int tp_get_old_state(tp_ctx *ctx, double *u_host);
+int tp_restore_state(tp_ctx *ctx);                          /* u <- u_  (thermalmodel.py:179: u.assign(u_)) */
+/* two-phase saturation guard of the time loop (thermalmodel.py:193-229): min/max of S_o over the owned
+ * cells of this rank, and the clamp to [0,1]; both on the device. */
+int tp_saturation_range(tp_ctx *ctx, double *smin, double *smax);
+int tp_clamp_saturation(tp_ctx *ctx);
 
 /* assembly: F(u) and J = dF/du (what TSFC/PyOP2 kernels + MatSetValues do in the reference). */
 int tp_residual(tp_ctx *ctx, double *norm2);               /* R <- F(u); ||F||_2 over all ranks */

@@ -46,11 +46,23 @@ class OracleEngine:
     def get_state(self):
         return self.u.copy()
 
-    def set_old(self, u):
-        self.prob.set_old(np.array(u, dtype=float))
+    def set_old(self, u=None):
+        self.prob.set_old(self.u if u is None else np.array(u, dtype=float))
 
     def set_dt(self, dt):
         self.prob.set_dt(dt)
+
+    def get_old_state(self):
+        return self.prob.u_old.copy()
+
+    def restore_state(self):
+        self.u = self.prob.u_old.copy()
+
+    def saturation_range(self):
+        return float(self.u[2].min()), float(self.u[2].max())
+
+    def clamp_saturation(self):
+        self.u[2] = np.clip(self.u[2], 0.0, 1.0)
 
     # pieces, exposed for parity tests ------------------------------------------------------
     def residual(self, u=None):

@@ -260,6 +260,36 @@ int tp_set_dt(tp_ctx *c, double dt) {
     TP_API_END
 }
 
+int tp_get_old_state(tp_ctx *c, double *u_host) {
+    TP_API_BEGIN
+    TP_REQUIRE(c && u_host, "null argument");
+    TP_HIP(hipStreamSynchronize(c->stream));
+    TP_HIP(hipMemcpy(u_host, c->u_old.p, sizeof(double) * c->u_old.n, hipMemcpyDeviceToHost));
+    TP_API_END
+}
+
+int tp_restore_state(tp_ctx *c) {
+    TP_API_BEGIN
+    TP_REQUIRE(c && c->have_old, "no old state to restore");
+    vec_copy(c, c->u_old.p, c->u.p, (long)c->u.n);
+    TP_API_END
+}
+
+int tp_saturation_range(tp_ctx *c, double *smin, double *smax) {
+    TP_API_BEGIN
+    TP_REQUIRE(c && smin && smax, "null argument");
+    TP_REQUIRE(c->nph == 2, "saturation exists only in the two-phase model");
+    field_minmax(c, c->u.p + 2 * c->g.ntot, smin, smax);
+    TP_API_END
+}
+
+int tp_clamp_saturation(tp_ctx *c) {
+    TP_API_BEGIN
+    TP_REQUIRE(c && c->nph == 2, "saturation exists only in the two-phase model");
+    field_clamp01(c, c->u.p + 2 * c->g.ntot);
+    TP_API_END
+}
+
 int tp_residual(tp_ctx *c, double *norm2_out) {
     TP_API_BEGIN
     if (c->comm) halo_exchange(c, c->g, c->u.p, c->b, c->g.ntot);

@@ -170,6 +170,8 @@ void multi_dot(tp_ctx *c, int nf, const double *V, long vstride, int k, const do
 void multi_axpy(tp_ctx *c, int nf, const double *V, long vstride, int k, const double *hcoef_host, double sign,
                 double *w);          // w += sign * sum_i h_i V_i
 double norm2(tp_ctx *c, int nf, const double *x);
+void field_minmax(tp_ctx *c, const double *x, double *lo, double *hi);
+void field_clamp01(tp_ctx *c, double *x);
 // stencil operators
 void spmv_block(tp_ctx *c, const double *J, const double *x, double *y);                 // y = J x
 void resid_block_cols(tp_ctx *c, const double *J, const double *x, const double *y, int ncols, double *r);  // r = x - J[:, :ncols] y

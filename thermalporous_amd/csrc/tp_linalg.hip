@@ -2,6 +2,7 @@
 // SURVEY.md 2.2 N3, N4, N9, N10).  All HBM-bound; one thread per owned cell, consecutive lanes on
 // consecutive cells, every matrix plane streamed exactly once per product.
 #include "tp_common.hpp"
+#include <algorithm>
 
 namespace tp {
 
@@ -149,6 +150,50 @@ void multi_axpy(tp_ctx *c, int nf, const double *V, long vstride, int k, const d
     TP_HIP(hipGetLastError());
     // the host buffer may be reused by the caller right away
     TP_HIP(hipStreamSynchronize(c->stream));
+}
+
+// ---- saturation guard (thermalmodel.py:193-229): min/max and clamp of one field over owned cells -----
+__global__ __launch_bounds__(256) void k_minmax(GridDev g, const double *x, double *partial) {
+    __shared__ double smin[4], smax[4];
+    double lo = 1e300, hi = -1e300;
+    for (long i = (long)blockIdx.x * blockDim.x + threadIdx.x; i < g.nown; i += (long)gridDim.x * blockDim.x) {
+        const double v = x[g.np + i];
+        lo = fmin(lo, v);
+        hi = fmax(hi, v);
+    }
+#pragma unroll
+    for (int o = 32; o > 0; o >>= 1) {
+        lo = fmin(lo, __shfl_down(lo, o, 64));
+        hi = fmax(hi, __shfl_down(hi, o, 64));
+    }
+    if ((threadIdx.x & 63) == 0) { smin[threadIdx.x >> 6] = lo; smax[threadIdx.x >> 6] = hi; }
+    __syncthreads();
+    if (threadIdx.x == 0) {
+        partial[2 * blockIdx.x] = fmin(fmin(smin[0], smin[1]), fmin(smin[2], smin[3]));
+        partial[2 * blockIdx.x + 1] = fmax(fmax(smax[0], smax[1]), fmax(smax[2], smax[3]));
+    }
+}
+__global__ void k_clamp01(GridDev g, double *x) {
+    const long i = (long)blockIdx.x * blockDim.x + threadIdx.x;
+    if (i >= g.nown) return;
+    const double v = x[g.np + i];
+    x[g.np + i] = fmax(fmin(v, 1.0), 0.0);
+}
+
+void field_minmax(tp_ctx *c, const double *x, double *lo, double *hi) {
+    const int nb = (int)std::min<long>(512, (c->g.nown + 255) / 256);
+    if ((long)c->gs_partial.n < 2L * nb) c->gs_partial.alloc(4096);
+    hipLaunchKernelGGL(k_minmax, dim3(nb), dim3(256), 0, c->stream, c->g, x, c->gs_partial.p);
+    std::vector<double> h(2 * nb);
+    TP_HIP(hipMemcpyAsync(h.data(), c->gs_partial.p, sizeof(double) * 2 * nb, hipMemcpyDeviceToHost, c->stream));
+    TP_HIP(hipStreamSynchronize(c->stream));
+    *lo = 1e300; *hi = -1e300;
+    for (int i = 0; i < nb; ++i) { *lo = std::min(*lo, h[2 * i]); *hi = std::max(*hi, h[2 * i + 1]); }
+}
+
+void field_clamp01(tp_ctx *c, double *x) {
+    hipLaunchKernelGGL(k_clamp01, grid_for(c->g.nown), dim3(256), 0, c->stream, c->g, x);
+    TP_HIP(hipGetLastError());
 }
 
 // ---- block stencil mat-vec: y = J x  (MatMult) ----------------------------------------------------

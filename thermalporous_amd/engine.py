@@ -55,7 +55,8 @@ class tp_solve_info(C.Structure):
 API_SYMBOLS = (
     "tp_last_error", "tp_version", "tp_create", "tp_destroy", "tp_set_options", "tp_comm_unique_id", "tp_comm_init",
     "tp_set_field", "tp_finalize_fields", "tp_set_sources", "tp_set_state", "tp_get_state", "tp_set_old_state",
-    "tp_set_dt", "tp_residual", "tp_jacobian", "tp_get_residual", "tp_export_jacobian", "tp_export_schur",
+    "tp_set_dt", "tp_get_old_state", "tp_restore_state", "tp_saturation_range", "tp_clamp_saturation",
+    "tp_residual", "tp_jacobian", "tp_get_residual", "tp_export_jacobian", "tp_export_schur",
     "tp_well_rates", "tp_vec_create", "tp_vec_set", "tp_vec_get", "tp_vec_copy_residual", "tp_spmv", "tp_pc_setup",
     "tp_pc_apply", "tp_stage1_update", "tp_stage1_apply", "tp_ilu0_factor", "tp_ilu0_solve", "tp_amg_setup",
     "tp_amg_vcycle", "tp_schur_apply", "tp_fgmres", "tp_newton_solve", "tp_time_kernel", "tp_amg_info",
@@ -222,6 +223,22 @@ class HipEngine:
     def set_dt(self, dt):
         self._ck(self.lib.tp_set_dt(self.ctx, C.c_double(float(dt))))
 
+    def get_old_state(self):
+        out = np.empty(self.b*self.ntot)
+        self._ck(self.lib.tp_get_old_state(self.ctx, _dptr(out)))
+        return self._strip_halo(out, self.b).copy()
+
+    def restore_state(self):
+        self._ck(self.lib.tp_restore_state(self.ctx))
+
+    def saturation_range(self):
+        lo, hi = C.c_double(), C.c_double()
+        self._ck(self.lib.tp_saturation_range(self.ctx, C.byref(lo), C.byref(hi)))
+        return lo.value, hi.value
+
+    def clamp_saturation(self):
+        self._ck(self.lib.tp_clamp_saturation(self.ctx))
+
     def residual(self, u=None):
         if u is not None:
             self.set_state(u)
@@ -289,6 +306,19 @@ class HipEngine:
 
     def ilu_solve(self, x, y):
         self._ck(self.lib.tp_ilu0_solve(self.ctx, self.vec(x), self.vec(y)))
+
+    def schur_apply(self, x, y):
+        self._ck(self.lib.tp_schur_apply(self.ctx, self.vec(x), self.vec(y)))
+
+    def vec_axpby(self, out, a, x, b, y):
+        """out = a*x + b*y through the host (test/plug-in convenience, not on the hot path)."""
+        self.vec_set(out, a*self._full(self.vec_get(x)) + b*self._full(self.vec_get(y)))
+
+    def _full(self, owned):
+        """Owned slab part -> global-shaped array (single-slab engines only)."""
+        if self.nranks != 1:
+            raise EngineError("host-side vector algebra is only available on single-slab engines")
+        return owned
 
     def amg_vcycle(self, which, b, fb, x, fx):
         self._ck(self.lib.tp_amg_vcycle(self.ctx, which, fb, self.vec(b), fx, self.vec(x)))

@@ -1,0 +1,143 @@
+"""Preconditioner plug-in classes: the PCBase surface of the reference on top of the C ABI.
+
+Mirrors /root/reference/thermalporous/preconditioners.py:
+    CPRStage1PC              :335-906    initialize :339, update :875-878, apply :881-903
+    CPTRStage1PC             :1243-1571  initialize :1247, update :1545-1548, apply :1550-1567
+    ConvDiffSchurPC          :11-163     (single-phase S~; apply :152-155)
+    ConvDiffSchurTwoPhasesPC :165-333    (two-phase S~; update :318-319, apply :321-324)
+In the reference these are instantiated by PETSc's PCPYTHON from the option
+``-<prefix>pc_python_type`` and receive a petsc4py ``PC`` plus PETSc ``Vec``s.  Here ``pc`` is the light
+``PC`` handle below (options prefix + appctx + compute engine) and ``x``/``y`` are names of device
+vectors of the engine; the arithmetic of every method is a HIP kernel sequence behind one C-ABI call:
+
+    initialize/update -> tp_stage1_update   (sub-block extraction is zero-copy on the stencil-of-blocks
+                                             Jacobian, Quasi-/True-IMPES row operation, AMG set-up --
+                                             no extra UFL assemblies, no SpGEMM)
+    apply             -> tp_stage1_apply    r_p = x_p - D_ps D_ss^-1 x_s ; y_p = V-cycle(r_p) ; y_s = 0
+    ConvDiffSchur*.apply -> tp_schur_apply  one V-cycle on S~
+
+The production path does not go through Python per Krylov iteration (tp_newton_solve runs the whole
+Newton/FGMRES loop natively); these classes exist so that code written against the reference's PC
+API -- and the tests -- can drive the same stages one call at a time.  ``CompositePC`` reproduces
+PCCOMPOSITE multiplicative("python,bjacobi") from the pieces.
+"""
+
+
+class PC():
+    """Minimal stand-in for the petsc4py PC handed to PCBase methods."""
+
+    def __init__(self, engine, appctx, prefix=""):
+        self.engine = engine
+        self.appctx = appctx
+        self._prefix = prefix
+
+    def getOptionsPrefix(self):
+        return self._prefix
+
+
+class PCBase():
+    """Firedrake's PCBase protocol: setUp -> initialize (first call) / update (later calls)."""
+
+    def __init__(self):
+        self.initialized = False
+
+    def get_appctx(self, pc):
+        return pc.appctx
+
+    def setUp(self, pc):
+        if self.initialized:
+            self.update(pc)
+        else:
+            self.initialize(pc)
+            self.initialized = True
+
+    def view(self, pc, viewer=None):
+        print("%s (decoupling %s) on the HIP engine" % (type(self).__name__, getattr(self, "decoup", "-")))
+
+
+class CPRStage1PC(PCBase):
+    '''
+    1st stage solver for constrained pressure residual
+    '''
+    kind = "cpr"
+
+    def initialize(self, pc):
+        appctx = self.get_appctx(pc)
+        self.decoup = appctx["decoup"]                 # (:370)
+        if self.decoup not in ("No", "QI", "TI"):
+            raise NotImplementedError("decoupling %r: QI_temp/TI_temp are experimental variants outside the "
+                                      "hot path" % self.decoup)
+        eng = pc.engine
+        if eng.opts["pc"] != self.kind or eng.opts["decoup"] != self.decoup:
+            eng.set_options(pc=self.kind, decoup=self.decoup)
+        self.update(pc)
+
+    def update(self, pc):
+        # assemble_blocks + create_decoup + pc_schur.setOperators(Atildepp)   (:875-878)
+        pc.engine.pc_setup()
+
+    def apply(self, pc, x, y):
+        # x_p - Aps*inv(Dss)*x_s -> V-cycle -> y_p ; y_nonp = 0                (:881-903)
+        pc.engine.stage1_apply(x, y)
+
+    # should not be used
+    applyTranspose = apply
+
+
+class CPTRStage1PC(CPRStage1PC):
+    '''
+    1st stage solver for constrained pressure-temperature residual
+    '''
+    kind = "cptr"
+
+    def initialize(self, pc):
+        appctx = self.get_appctx(pc)
+        if appctx.get("vector"):
+            raise NotImplementedError("vector=True (interleaved p,T; pc_cptramg*/pc_cptrlu*) is outside the hot path")
+        CPRStage1PC.initialize(self, pc)
+
+
+class ConvDiffSchurTwoPhasesPC(PCBase):
+    """Schur-complement approximation S~ = temperature convection-diffusion operator frozen at the
+    current Newton state (:165-333); assembled by the fused assembly kernel as a by-product."""
+
+    def initialize(self, pc):
+        if pc.engine.opts["pc"] != "cptr":
+            raise NotImplementedError("S~ is assembled for pc_cptr only")
+        self.update(pc)
+
+    def update(self, pc):
+        pc.engine.pc_setup()          # re-assembles nothing: S~ comes with the Jacobian (tp_jacobian)
+
+    def apply(self, pc, X, Y):
+        pc.engine.schur_apply(X, Y)   # one V-cycle on S~, temperature field
+
+    applyTranspose = apply
+
+
+class ConvDiffSchurPC(ConvDiffSchurTwoPhasesPC):
+    """Single-phase variant (:11-163), used by the reference's pc_fieldsplit_cd preset
+    (singlephase.py:309-319), which is listed as a 'next' row."""
+
+    def initialize(self, pc):
+        raise NotImplementedError("pc_fieldsplit_cd (single-phase block preconditioner) is not on the hot path yet")
+
+
+class CompositePC():
+    """PCCOMPOSITE multiplicative("python,bjacobi") (singlephase.py:341-343) assembled from the
+    stage objects: y = B1 x ; r = x - J y ; y += ILU0(r).  Used by tests to show that driving the
+    stages through the PCBase API reproduces tp_pc_apply."""
+
+    def __init__(self, stage1):
+        self.stage1 = stage1
+
+    def setUp(self, pc):
+        self.stage1.setUp(pc)
+
+    def apply(self, pc, x, y):
+        eng = pc.engine
+        self.stage1.apply(pc, x, y)
+        eng.spmv(y, "_cmp_Jy")
+        eng.vec_axpby("_cmp_r", 1.0, x, -1.0, "_cmp_Jy")
+        eng.ilu_solve("_cmp_r", "_cmp_z")
+        eng.vec_axpby(y, 1.0, y, 1.0, "_cmp_z")

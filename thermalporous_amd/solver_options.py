@@ -1,0 +1,85 @@
+"""PETSc-style ``solver_parameters`` of the reference -> options of the compute engine.
+
+The reference configures its whole linear/nonlinear stack through PETSc option dicts
+(singlephase.py:289-354,410-439; twophase.py:416-433,531-597,929-997).  The hot path honours the
+subset that selects the solvers it implements and rejects everything else loudly:
+
+  snes_type newtonls  (line search `basic`: Firedrake's default, not settable in the reference)
+  ksp_type fgmres|gmres (right preconditioning), ksp_rtol/atol/max_it, ksp_gmres_restart
+  pc_type composite, pc_composite_type multiplicative, pc_composite_pcs "python,bjacobi"
+     sub_0_pc_python_type  ...CPRStage1PC | ...CPTRStage1PC   sub_0_cpr_decoup  No|QI|TI
+     sub_0_cpr_stage1*     boomeramg V-cycle / fieldsplit-schur-FULL with ConvDiffSchurTwoPhasesPC
+     sub_1_sub_pc_type ilu, sub_1_sub_pc_factor_levels 0, sub_1_pc_bjacobi_blocks
+
+Defaults the reference inherits silently from Firedrake/PETSc are fixed here explicitly
+(SURVEY.md 8c): ksp_rtol 1e-7 (Firedrake), snes_rtol 1e-8, snes_atol 1e-50, snes_stol 1e-8,
+ksp_atol 1e-50.  Build-specific tuning keys (not PETSc): amg_omega, amg_nu, amg_min_cells,
+ilu_tile.  Two-phase string presets are layered on plain Newton-Krylov, not on the reference's
+experimental FAS nonlinear preconditioner (twophase.py:927; needs mesh hierarchies + MUMPS).
+"""
+
+_IGNORED = {"snes_monitor", "snes_converged_reason", "ksp_converged_reason", "ksp_view", "snes_view", "ksp_monitor",
+            "mat_type", "ksp_pc_side", "snes_linesearch_type", "ksp_monitor_residuals"}
+
+_V_CYCLE = {"ksp_type": "preonly", "pc_type": "hypre", "pc_hypre_type": "boomeramg",
+            "pc_hypre_boomeramg_max_iter": 1}
+
+
+def _flatten(d, prefix=""):
+    """PETSc semantics: a nested dict is a prefix (``"sub_0_cpr_stage1": v_cycle``)."""
+    out = {}
+    for k, v in d.items():
+        if isinstance(v, dict):
+            out.update(_flatten(v, prefix + k + "_"))
+        else:
+            out[prefix + k] = v
+    return out
+
+
+def engine_options(solver_parameters, model_name, decoup="No"):
+    from .engine import DEFAULT_OPTS
+    sp = _flatten(dict(solver_parameters))
+    o = dict(DEFAULT_OPTS)
+    o["decoup"] = decoup
+    build_keys = ("amg_omega", "amg_nu", "amg_min_cells", "ilu_tile")
+    for k in build_keys:
+        if k in sp:
+            o[k] = sp.pop(k)
+    if sp.get("snes_type", "newtonls") != "newtonls":
+        raise NotImplementedError("snes_type %r: only newtonls is on the hot path" % sp["snes_type"])
+    if sp.get("ksp_type", "gmres") not in ("fgmres", "gmres"):
+        raise NotImplementedError("ksp_type %r: only (f)gmres with right preconditioning" % sp["ksp_type"])
+    if sp.get("ksp_type", "gmres") == "gmres" and sp.get("ksp_pc_side", "right") != "right":
+        raise NotImplementedError("left-preconditioned GMRES is not implemented")
+    for k_src, k_dst in (("ksp_rtol", "ksp_rtol"), ("ksp_atol", "ksp_atol"), ("ksp_max_it", "ksp_max_it"),
+                         ("ksp_gmres_restart", "ksp_restart"), ("snes_max_it", "snes_max_it"),
+                         ("snes_rtol", "snes_rtol"), ("snes_atol", "snes_atol"), ("snes_stol", "snes_stol")):
+        if k_src in sp:
+            o[k_dst] = sp[k_src]
+    if sp.get("pc_type") != "composite" or sp.get("pc_composite_type", "multiplicative") != "multiplicative" \
+            or sp.get("pc_composite_pcs") != "python,bjacobi":
+        raise NotImplementedError(
+            "only the composite multiplicative 'python,bjacobi' preconditioners (pc_cpr*, pc_cptr) are on the hot "
+            "path; got pc_type=%r pc_composite_pcs=%r" % (sp.get("pc_type"), sp.get("pc_composite_pcs")))
+    pytype = str(sp.get("sub_0_pc_python_type", ""))
+    if pytype.endswith("CPRStage1PC"):
+        o["pc"] = "cpr"
+    elif pytype.endswith("CPTRStage1PC"):
+        if model_name != "Two-phase":
+            raise NotImplementedError("CPTRStage1PC needs the two-phase model")
+        o["pc"] = "cptr"
+        if sp.get("sub_0_cpr_stage1_pc_type") != "fieldsplit":
+            raise NotImplementedError("CPTRStage1PC is implemented with the fieldsplit-Schur stage-1 solver of "
+                                      "pc_cptr; system-AMG/LU variants (pc_cptramg*, pc_cptrlu*) are not")
+    else:
+        raise NotImplementedError("sub_0_pc_python_type %r" % pytype)
+    if o["decoup"] not in ("No", "QI", "TI"):
+        raise NotImplementedError("decoupling %r (QI_temp/TI_temp are experimental variants)" % o["decoup"])
+    if sp.get("sub_1_sub_pc_type", "ilu") != "ilu" or int(sp.get("sub_1_sub_pc_factor_levels", 0)) != 0:
+        raise NotImplementedError("stage 2 must be ILU(0)")
+    known_prefixes = ("sub_0_", "sub_1_", "pc_", "ksp_", "snes_")
+    for k in sp:
+        if k in _IGNORED or k.startswith(known_prefixes):
+            continue
+        raise KeyError("unknown solver parameter %r" % k)
+    return o
