@@ -73,7 +73,8 @@ typedef struct tp_options {
     double  amg_omega;       /* damped-Jacobi weight of the AMG smoother */
     int32_t amg_nu;          /* pre/post smoothing sweeps */
     int32_t amg_min_cells;   /* coarsest-grid size (dense solve) */
-    int32_t ilu_t1, ilu_t2;  /* bjacobi tile extent along axes 1,2 (t1*t2 <= 64; axis 0 whole) */
+    int32_t ilu_t1, ilu_t2;  /* bjacobi tile extent along axes 1,2 (t1*t2 <= 64: one wavefront per tile) */
+    int32_t ilu_t0;          /* tile extent along axis 0 (<= 0: the whole line) */
 } tp_options;
 
 /* Result of one nonlinear solve (SNES iteration number / linear iterations / reason:

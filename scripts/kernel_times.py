@@ -1,0 +1,17 @@
+"""Development probe: kernel timings on C4 after a few ramp steps."""
+import sys, os, time
+sys.path.insert(0, os.path.join(os.path.dirname(os.path.abspath(__file__)), ".."))
+import bench
+tile = eval(sys.argv[1]) if len(sys.argv) > 1 else None
+m = bench.make_model("c4")
+if tile:
+    m.engine.set_options(ilu_tile=tile)
+m.start()
+t = time.time()
+for i in range(4):
+    print(m.step(), flush=True)
+print("4 steps %.3fs" % (time.time() - t), "failed", m.failed_solves)
+e = m.engine
+e.lib.tp_jacobian(e.ctx); e.pc_setup()
+for w, nm in enumerate(["spmv", "ilu_solve", "amg_vcycle", "assembly", "pc_apply"]):
+    print("%-12s %.3f ms" % (nm, e.time_kernel(w, 20)), flush=True)

@@ -38,6 +38,7 @@ CASES = [
     ("c4_2ph_3d", cases.c4_spe10_3d, dict(Nx=7, Ny=13, Nz=9, nphase=2), dict(pc="cptr")),
     ("c4_1ph_3d", cases.c4_spe10_3d, dict(Nx=7, Ny=13, Nz=9, nphase=1), dict(pc="cpr", decoup="TI")),
     ("c4_2ph_3d_cprQI", cases.c4_spe10_3d, dict(Nx=9, Ny=10, Nz=5, nphase=2), dict(pc="cpr", decoup="QI")),
+    ("c4_2ph_3d_tiles", cases.c4_spe10_3d, dict(Nx=11, Ny=13, Nz=17, nphase=2), dict(pc="cptr", ilu_tile=(5, 4, 7))),
 ]
 
 

@@ -13,8 +13,17 @@
 //     A_c[d]  = a_d(f) + w+(g-) a_d(g-) + w-(g+) a_d(g+)            (cross slots),
 //     A_c[0]  = -sum(off-diagonals) + rho(f) + w+(g-) rho(g-) + w-(g+) rho(g+),  rho = row sums.
 //   V(nu,nu), damped Jacobi, dense inverse on the coarsest grid.
+//
+// The V-cycle is launch-latency-bound below the first few levels (a level with < 10^5 cells is a
+// < 4 us kernel), so it is organised to minimise launches:
+//   * big levels: 4 fused kernels per level for V(2,2) -- [two Jacobi sweeps from a zero guess],
+//     [residual + restriction], [prolongation + first post-sweep], [last post-sweep];
+//   * all levels at or below `tail_cells` cells run inside ONE single-workgroup kernel (down-sweep,
+//     dense coarse solve, up-sweep) with workgroup barriers between phases -- for the small 2-D
+//     configurations the whole V-cycle is a single launch.
 #include "tp_common.hpp"
 #include <algorithm>
+#include <cstdlib>
 
 namespace tp {
 
@@ -27,6 +36,7 @@ __device__ __forceinline__ void cell_ijk(const GridDev &g, long tid, int &i0, in
     i0 = rem - i1 * g.n0;
 }
 
+// ---- set-up kernels --------------------------------------------------------------------------------
 // interpolation weights of every cell w.r.t. axis a (only odd cells are used) + invd = omega/diag
 __global__ void k_amg_weights(GridDev g, Stencil A, int axis, double omega, double *wm, double *wp, double *invd) {
     const long tid = (long)blockIdx.x * blockDim.x + threadIdx.x;
@@ -82,84 +92,8 @@ __global__ void k_amg_coarsen(GridDev gf, GridDev gc, Stencil A, int axis, const
     for (int s = 0; s < 7; ++s) Ac[(long)s * gc.ntot + cc] = out[s];
 }
 
-// x = invd * b  (first Jacobi sweep from a zero guess)
-__global__ void k_amg_jacobi0(GridDev g, const double *invd, const double *b, double *x) {
-    const long tid = (long)blockIdx.x * blockDim.x + threadIdx.x;
-    if (tid >= g.nown) return;
-    const long c = g.np + tid;
-    x[c] = invd[c] * b[c];
-}
-
-// xout = x + invd * (b - A x)
-__global__ __launch_bounds__(256) void k_amg_jacobi(GridDev g, Stencil A, const double *__restrict__ invd,
-                                                    const double *__restrict__ b, const double *__restrict__ x,
-                                                    double *__restrict__ xout) {
-    const long tid = (long)blockIdx.x * blockDim.x + threadIdx.x;
-    if (tid >= g.nown) return;
-    const long c = g.np + tid;
-    const long off[7] = {0, -1, 1, -(long)g.n0, (long)g.n0, -g.np, g.np};
-    double s = 0.0;
-#pragma unroll
-    for (int k = 0; k < 7; ++k) s += A.slot(k)[c] * x[c + off[k]];
-    xout[c] = x[c] + invd[c] * (b[c] - s);
-}
-
-// r = b - A x on the fine level, written to r (plain residual)
-__global__ __launch_bounds__(256) void k_amg_resid(GridDev g, Stencil A, const double *__restrict__ b,
-                                                   const double *__restrict__ x, double *__restrict__ r) {
-    const long tid = (long)blockIdx.x * blockDim.x + threadIdx.x;
-    if (tid >= g.nown) return;
-    const long c = g.np + tid;
-    const long off[7] = {0, -1, 1, -(long)g.n0, (long)g.n0, -g.np, g.np};
-    double s = 0.0;
-#pragma unroll
-    for (int k = 0; k < 7; ++k) s += A.slot(k)[c] * x[c + off[k]];
-    r[c] = b[c] - s;
-}
-
-// rc = P^T r : one thread per coarse cell
-__global__ void k_amg_restrict(GridDev gf, GridDev gc, int axis, const double *wm, const double *wp,
-                               const double *r, double *rc) {
-    const long tid = (long)blockIdx.x * blockDim.x + threadIdx.x;
-    if (tid >= gc.nown) return;
-    int I[3];
-    cell_ijk(gc, tid, I[0], I[1], I[2]);
-    int F[3] = {I[0], I[1], I[2]};
-    F[axis] = 2 * I[axis];
-    const int nfa = axis == 0 ? gf.n0 : (axis == 1 ? gf.n1 : gf.n2);
-    const long stride = axis == 0 ? 1 : (axis == 1 ? gf.n0 : gf.np);
-    const long f = gf.np + (long)F[0] + (long)gf.n0 * F[1] + gf.np * F[2];
-    double v = r[f];
-    if (F[axis] - 1 >= 0) v += wp[f - stride] * r[f - stride];
-    if (F[axis] + 1 < nfa) v += wm[f + stride] * r[f + stride];
-    rc[gc.np + tid] = v;
-}
-
-// x += P ec : one thread per fine cell
-__global__ void k_amg_prolong_add(GridDev gf, GridDev gc, int axis, const double *wm, const double *wp,
-                                  const double *ec, double *x) {
-    const long tid = (long)blockIdx.x * blockDim.x + threadIdx.x;
-    if (tid >= gf.nown) return;
-    int F[3];
-    cell_ijk(gf, tid, F[0], F[1], F[2]);
-    const long c = gf.np + tid;
-    int I[3] = {F[0], F[1], F[2]};
-    I[axis] = F[axis] >> 1;
-    const long ci = gc.np + (long)I[0] + (long)gc.n0 * I[1] + gc.np * I[2];
-    const long cstride = axis == 0 ? 1 : (axis == 1 ? gc.n0 : gc.np);
-    const int nca = axis == 0 ? gc.n0 : (axis == 1 ? gc.n1 : gc.n2);
-    double e;
-    if ((F[axis] & 1) == 0) e = ec[ci];
-    else {
-        e = wm[c] * ec[ci];
-        if (I[axis] + 1 < nca) e += wp[c] * ec[ci + cstride];
-    }
-    x[c] += e;
-}
-
-// coarsest grid: dense inverse by Gauss-Jordan in one workgroup (n <= 64 ... a few hundred)
+// coarsest grid: dense inverse by Gauss-Jordan in one workgroup (diagonally dominant: no pivoting)
 __global__ void k_amg_dense_inverse(GridDev g, Stencil A, int n, double *M, double *Minv) {
-    // build dense M from the stencil
     const long off[7] = {0, -1, 1, -(long)g.n0, (long)g.n0, -g.np, g.np};
     for (int e = threadIdx.x; e < n * n; e += blockDim.x) { M[e] = 0.0; Minv[e] = (e / n == e % n) ? 1.0 : 0.0; }
     __syncthreads();
@@ -184,7 +118,6 @@ __global__ void k_amg_dense_inverse(GridDev g, Stencil A, int n, double *M, doub
             const int r = e / n, q = e % n;
             if (r == p) continue;
             const double fct = M[(long)r * n + p];
-            // column p of M must stay readable for every q: update Minv fully, M for q != p
             Minv[(long)r * n + q] -= fct * Minv[(long)p * n + q];
             if (q != p) M[(long)r * n + q] -= fct * M[(long)p * n + q];
         }
@@ -195,12 +128,233 @@ __global__ void k_amg_dense_inverse(GridDev g, Stencil A, int n, double *M, doub
     }
 }
 
-__global__ void k_amg_dense_apply(GridDev g, int n, const double *Minv, const double *b, double *x) {
-    const int r = blockIdx.x * blockDim.x + threadIdx.x;
-    if (r >= n) return;
+// ---- per-cell building blocks of the cycle (shared by the per-level kernels and the tail kernel) ------
+struct LevelDev {
+    GridDev g;
+    Stencil op;
+    const double *invd, *wm, *wp;
+    double *b, *x, *x2, *e;
+    int axis;
+};
+
+__device__ __forceinline__ void nb_offsets(const GridDev &g, long (&off)[7]) {
+    off[0] = 0; off[1] = -1; off[2] = 1; off[3] = -(long)g.n0; off[4] = g.n0; off[5] = -g.np; off[6] = g.np;
+}
+
+// two damped-Jacobi sweeps from a zero initial guess:  x1 = invd b ;  x2 = x1 + invd (b - A x1)
+__device__ __forceinline__ double pre2_cell(const LevelDev &L, const double *__restrict__ b, long tid) {
+    const long c = L.g.np + tid;
+    long off[7];
+    nb_offsets(L.g, off);
     double s = 0.0;
-    for (int q = 0; q < n; ++q) s += Minv[(long)r * n + q] * b[g.np + q];
-    x[g.np + r] = s;
+#pragma unroll
+    for (int k = 0; k < 7; ++k) {
+        const long n = c + off[k];
+        s += L.op.slot(k)[c] * (L.invd[n] * b[n]);
+    }
+    const double x1 = L.invd[c] * b[c];
+    return x1 + L.invd[c] * (b[c] - s);
+}
+
+__device__ __forceinline__ double jacobi_cell(const LevelDev &L, const double *__restrict__ b,
+                                              const double *__restrict__ x, long tid) {
+    const long c = L.g.np + tid;
+    long off[7];
+    nb_offsets(L.g, off);
+    double s = 0.0;
+#pragma unroll
+    for (int k = 0; k < 7; ++k) s += L.op.slot(k)[c] * x[c + off[k]];
+    return x[c] + L.invd[c] * (b[c] - s);
+}
+
+__device__ __forceinline__ double resid_at(const LevelDev &L, const double *__restrict__ b,
+                                           const double *__restrict__ x, long c) {
+    long off[7];
+    nb_offsets(L.g, off);
+    double s = 0.0;
+#pragma unroll
+    for (int k = 0; k < 7; ++k) s += L.op.slot(k)[c] * x[c + off[k]];
+    return b[c] - s;
+}
+
+// (P^T (b - A x)) at coarse cell tidc
+__device__ __forceinline__ double resid_restrict_cell(const LevelDev &Lf, const GridDev &gc,
+                                                      const double *__restrict__ b, const double *__restrict__ x,
+                                                      long tidc) {
+    int I[3];
+    cell_ijk(gc, tidc, I[0], I[1], I[2]);
+    const int a = Lf.axis;
+    int F[3] = {I[0], I[1], I[2]};
+    F[a] = 2 * I[a];
+    const GridDev &gf = Lf.g;
+    const int nfa = a == 0 ? gf.n0 : (a == 1 ? gf.n1 : gf.n2);
+    const long stride = a == 0 ? 1 : (a == 1 ? gf.n0 : gf.np);
+    const long f = gf.np + (long)F[0] + (long)gf.n0 * F[1] + gf.np * F[2];
+    double v = resid_at(Lf, b, x, f);
+    if (F[a] - 1 >= 0) v += Lf.wp[f - stride] * resid_at(Lf, b, x, f - stride);
+    if (F[a] + 1 < nfa) v += Lf.wm[f + stride] * resid_at(Lf, b, x, f + stride);
+    return v;
+}
+
+// (P ec) at fine cell (F0,F1,F2)
+__device__ __forceinline__ double prolong_at(const LevelDev &Lf, const GridDev &gc, const double *__restrict__ ec,
+                                             int F0, int F1, int F2) {
+    const int a = Lf.axis;
+    const int Fa = a == 0 ? F0 : (a == 1 ? F1 : F2);
+    int I0 = F0, I1 = F1, I2 = F2;
+    if (a == 0) I0 = F0 >> 1; else if (a == 1) I1 = F1 >> 1; else I2 = F2 >> 1;
+    const long ci = gc.np + (long)I0 + (long)gc.n0 * I1 + gc.np * I2;
+    if ((Fa & 1) == 0) return ec[ci];
+    const long c = Lf.g.np + (long)F0 + (long)Lf.g.n0 * F1 + Lf.g.np * F2;
+    const long cs = a == 0 ? 1 : (a == 1 ? gc.n0 : gc.np);
+    const int nca = a == 0 ? gc.n0 : (a == 1 ? gc.n1 : gc.n2);
+    double e = Lf.wm[c] * ec[ci];
+    if ((Fa >> 1) + 1 < nca) e += Lf.wp[c] * ec[ci + cs];
+    return e;
+}
+
+// coarse-grid correction fused with the first post-smoothing sweep:
+//   x' = x + P ec ;  out = x' + invd (b - A x')
+__device__ __forceinline__ double prolong_jacobi_cell(const LevelDev &Lf, const GridDev &gc,
+                                                      const double *__restrict__ b, const double *__restrict__ x,
+                                                      const double *__restrict__ ec, long tid) {
+    const GridDev &g = Lf.g;
+    int i0, i1, i2;
+    cell_ijk(g, tid, i0, i1, i2);
+    const long c = g.np + tid;
+    const double xc = x[c] + prolong_at(Lf, gc, ec, i0, i1, i2);
+    double s = Lf.op.slot(0)[c] * xc;
+    if (i0 > 0)        s += Lf.op.slot(1)[c] * (x[c - 1] + prolong_at(Lf, gc, ec, i0 - 1, i1, i2));
+    if (i0 < g.n0 - 1) s += Lf.op.slot(2)[c] * (x[c + 1] + prolong_at(Lf, gc, ec, i0 + 1, i1, i2));
+    if (i1 > 0)        s += Lf.op.slot(3)[c] * (x[c - g.n0] + prolong_at(Lf, gc, ec, i0, i1 - 1, i2));
+    if (i1 < g.n1 - 1) s += Lf.op.slot(4)[c] * (x[c + g.n0] + prolong_at(Lf, gc, ec, i0, i1 + 1, i2));
+    if (i2 > 0)        s += Lf.op.slot(5)[c] * (x[c - g.np] + prolong_at(Lf, gc, ec, i0, i1, i2 - 1));
+    if (i2 < g.n2 - 1) s += Lf.op.slot(6)[c] * (x[c + g.np] + prolong_at(Lf, gc, ec, i0, i1, i2 + 1));
+    return xc + Lf.invd[c] * (b[c] - s);
+}
+
+// ---- per-level kernels (big levels) -----------------------------------------------------------------
+__global__ __launch_bounds__(256) void k_amg_pre(LevelDev L, const double *b, int two, double *out) {
+    const long tid = (long)blockIdx.x * blockDim.x + threadIdx.x;
+    if (tid >= L.g.nown) return;
+    const long c = L.g.np + tid;
+    out[c] = two ? pre2_cell(L, b, tid) : L.invd[c] * b[c];
+}
+__global__ __launch_bounds__(256) void k_amg_jacobi(LevelDev L, const double *b, const double *x, double *out) {
+    const long tid = (long)blockIdx.x * blockDim.x + threadIdx.x;
+    if (tid >= L.g.nown) return;
+    out[L.g.np + tid] = jacobi_cell(L, b, x, tid);
+}
+__global__ __launch_bounds__(256) void k_amg_resid_restrict(LevelDev Lf, GridDev gc, const double *b,
+                                                            const double *x, double *rc) {
+    const long tid = (long)blockIdx.x * blockDim.x + threadIdx.x;
+    if (tid >= gc.nown) return;
+    rc[gc.np + tid] = resid_restrict_cell(Lf, gc, b, x, tid);
+}
+__global__ __launch_bounds__(256) void k_amg_prolong_jacobi(LevelDev Lf, GridDev gc, const double *b,
+                                                            const double *x, const double *ec, double *out) {
+    const long tid = (long)blockIdx.x * blockDim.x + threadIdx.x;
+    if (tid >= Lf.g.nown) return;
+    out[Lf.g.np + tid] = prolong_jacobi_cell(Lf, gc, b, x, ec, tid);
+}
+
+// unfused variants for the top levels, where the fused kernels are issue-bound rather than HBM-bound
+__global__ __launch_bounds__(256) void k_amg_resid(LevelDev L, const double *__restrict__ b,
+                                                   const double *__restrict__ x, double *__restrict__ r) {
+    const long tid = (long)blockIdx.x * blockDim.x + threadIdx.x;
+    if (tid >= L.g.nown) return;
+    r[L.g.np + tid] = resid_at(L, b, x, L.g.np + tid);
+}
+__global__ __launch_bounds__(256) void k_amg_restrict(LevelDev Lf, GridDev gc, const double *__restrict__ r,
+                                                      double *__restrict__ rc) {
+    const long tid = (long)blockIdx.x * blockDim.x + threadIdx.x;
+    if (tid >= gc.nown) return;
+    int I[3];
+    cell_ijk(gc, tid, I[0], I[1], I[2]);
+    const int a = Lf.axis;
+    int F[3] = {I[0], I[1], I[2]};
+    F[a] = 2 * I[a];
+    const GridDev &gf = Lf.g;
+    const int nfa = a == 0 ? gf.n0 : (a == 1 ? gf.n1 : gf.n2);
+    const long stride = a == 0 ? 1 : (a == 1 ? gf.n0 : gf.np);
+    const long f = gf.np + (long)F[0] + (long)gf.n0 * F[1] + gf.np * F[2];
+    double v = r[f];
+    if (F[a] - 1 >= 0) v += Lf.wp[f - stride] * r[f - stride];
+    if (F[a] + 1 < nfa) v += Lf.wm[f + stride] * r[f + stride];
+    rc[gc.np + tid] = v;
+}
+__global__ __launch_bounds__(256) void k_amg_prolong_add(LevelDev Lf, GridDev gc, const double *__restrict__ ec,
+                                                         double *x) {
+    const long tid = (long)blockIdx.x * blockDim.x + threadIdx.x;
+    if (tid >= Lf.g.nown) return;
+    int i0, i1, i2;
+    cell_ijk(Lf.g, tid, i0, i1, i2);
+    x[Lf.g.np + tid] += prolong_at(Lf, gc, ec, i0, i1, i2);
+}
+
+// ---- the tail: all small levels in one workgroup --------------------------------------------------------
+__global__ __launch_bounds__(1024) void k_amg_tail(const LevelDev *lv, int l0, int nlev, int nu, int ncoarse,
+                                                   const double *Minv, const double *b_top, double *e_top) {
+    const int T = blockDim.x, t = threadIdx.x;
+    // level descriptors live in LDS: every phase below starts with LDS reads, not a global round trip
+    static_assert(sizeof(LevelDev) % sizeof(long) == 0, "LevelDev must be a whole number of words");
+    __shared__ long slv_raw[40 * sizeof(LevelDev) / sizeof(long)];
+    {
+        const int wpl = (int)(sizeof(LevelDev) / sizeof(long));
+        const long *src = reinterpret_cast<const long *>(lv);
+        for (int i = l0 * wpl + t; i < nlev * wpl; i += T) slv_raw[i] = src[i];
+        __syncthreads();
+    }
+    lv = reinterpret_cast<const LevelDev *>(slv_raw);
+    // down-sweep
+    for (int l = l0; l < nlev - 1; ++l) {
+        const LevelDev L = lv[l];
+        const GridDev gc = lv[l + 1].g;
+        const double *b = (l == l0) ? b_top : L.b;
+        double *cur = L.x, *oth = L.x2;
+        for (long i = t; i < L.g.nown; i += T) cur[L.g.np + i] = nu >= 2 ? pre2_cell(L, b, i) : L.invd[L.g.np + i] * b[L.g.np + i];
+        __syncthreads();
+        for (int k = 2; k < nu; ++k) {
+            for (long i = t; i < L.g.nown; i += T) oth[L.g.np + i] = jacobi_cell(L, b, cur, i);
+            __syncthreads();
+            double *tmp = cur; cur = oth; oth = tmp;
+        }
+        double *rc = lv[l + 1].b;
+        for (long i = t; i < gc.nown; i += T) rc[gc.np + i] = resid_restrict_cell(L, gc, b, cur, i);
+        __syncthreads();
+    }
+    // coarsest grid: dense solve
+    {
+        const LevelDev Lc = lv[nlev - 1];
+        const double *b = (nlev - 1 == l0) ? b_top : Lc.b;
+        double *e = (nlev - 1 == l0) ? e_top : Lc.e;
+        for (int r = t; r < ncoarse; r += T) {
+            double s = 0.0;
+            for (int q = 0; q < ncoarse; ++q) s += Minv[(long)r * ncoarse + q] * b[Lc.g.np + q];
+            e[Lc.g.np + r] = s;
+        }
+        __syncthreads();
+    }
+    // up-sweep
+    for (int l = nlev - 2; l >= l0; --l) {
+        const LevelDev L = lv[l];
+        const GridDev gc = lv[l + 1].g;
+        const double *b = (l == l0) ? b_top : L.b;
+        double *out = (l == l0) ? e_top : L.e;
+        const double *ec = lv[l + 1].e;
+        // where the pre-smoothed iterate lives: x after an even number of extra sweeps, else x2
+        const int extra = nu >= 2 ? nu - 2 : 0;
+        double *src = (extra % 2 == 0) ? L.x : L.x2;
+        double *dst = (nu == 1) ? out : (src == L.x ? L.x2 : L.x);
+        for (long i = t; i < L.g.nown; i += T) dst[L.g.np + i] = prolong_jacobi_cell(L, gc, b, src, ec, i);
+        __syncthreads();
+        for (int k = 1; k < nu; ++k) {
+            src = dst;
+            dst = (k == nu - 1) ? out : (src == L.x ? L.x2 : L.x);
+            for (long i = t; i < L.g.nown; i += T) dst[L.g.np + i] = jacobi_cell(L, b, src, i);
+            __syncthreads();
+        }
+    }
 }
 
 // ---- host side ------------------------------------------------------------------------------------
@@ -221,6 +375,15 @@ static std::vector<int> schedule(const int n_[3], const double strength[3], int 
     return sched;
 }
 
+static LevelDev dev_of(const AmgLevel *L) {
+    LevelDev d;
+    d.g = L->g; d.op = L->op;
+    d.invd = L->invd.p; d.wm = L->wm.p; d.wp = L->wp.p;
+    d.b = L->b.p; d.x = L->x.p; d.x2 = L->x2.p; d.e = L->e.p;
+    d.axis = L->axis;
+    return d;
+}
+
 void amg_build(tp_ctx *c, Amg *&amg, const double strength[3]) {
     delete amg;
     amg = new Amg();
@@ -238,7 +401,7 @@ void amg_build(tp_ctx *c, Amg *&amg, const double strength[3]) {
             L->op.slot_stride = (long)nt;
         }
         L->invd.alloc(nt);
-        L->b.alloc(nt); L->x.alloc(nt); L->x2.alloc(nt); L->r.alloc(nt); L->e.alloc(nt);
+        L->b.alloc(nt); L->x.alloc(nt); L->x2.alloc(nt); L->e.alloc(nt);
         if (l < amg->sched.size()) {
             L->axis = amg->sched[l];
             L->wm.alloc(nt); L->wp.alloc(nt);
@@ -249,6 +412,13 @@ void amg_build(tp_ctx *c, Amg *&amg, const double strength[3]) {
     amg->ncoarse = (int)amg->lv.back()->g.nown;
     TP_REQUIRE(amg->ncoarse <= 1024, "coarsest AMG grid too large for the dense solve");
     amg->coarse_inv.alloc((size_t)2 * amg->ncoarse * amg->ncoarse);
+    // first level handled by the single-workgroup tail kernel
+    const long tail_cells = getenv("TP_AMG_TAIL_CELLS") ? atol(getenv("TP_AMG_TAIL_CELLS")) : 1024;
+    amg->fuse_below = getenv("TP_AMG_FUSE_BELOW") ? atol(getenv("TP_AMG_FUSE_BELOW")) : 200000;
+    amg->tail_level = (int)amg->lv.size() - 1;
+    for (size_t l = 0; l < amg->lv.size(); ++l)
+        if (amg->lv[l]->g.nown <= tail_cells) { amg->tail_level = (int)l; break; }
+    amg->lvdev.alloc(amg->lv.size() * sizeof(LevelDev));
 }
 
 void amg_setup(tp_ctx *c, Amg *amg, const Stencil &A0) {
@@ -270,49 +440,73 @@ void amg_setup(tp_ctx *c, Amg *amg, const Stencil &A0) {
     const int n = amg->ncoarse;
     hipLaunchKernelGGL(k_amg_dense_inverse, dim3(1), dim3(256), 0, c->stream, Lc->g, Lc->op, n, amg->coarse_inv.p,
                        amg->coarse_inv.p + (size_t)n * n);
+    std::vector<LevelDev> h;
+    for (auto *L : amg->lv) h.push_back(dev_of(L));
+    amg->lvhost.assign((const char *)h.data(), (const char *)h.data() + h.size() * sizeof(LevelDev));
+    TP_HIP(hipMemcpyAsync(amg->lvdev.p, amg->lvhost.data(), amg->lvhost.size(), hipMemcpyHostToDevice, c->stream));
     TP_HIP(hipGetLastError());
-}
-
-static void vcycle_rec(tp_ctx *c, Amg *amg, size_t l, const double *b, double *x) {
-    AmgLevel *L = amg->lv[l];
-    const GridDev &g = L->g;
-    const dim3 gr = grid_for(g.nown), bl(256);
-    if (L->axis < 0) {
-        const int n = amg->ncoarse;
-        hipLaunchKernelGGL(k_amg_dense_apply, grid_for(n, 64), dim3(64), 0, c->stream, g, n,
-                           amg->coarse_inv.p + (size_t)n * n, b, x);
-        return;
-    }
-    const int nu = std::max(1, c->opt.amg_nu);
-    // pre-smoothing from a zero guess: ping-pong so that the result lands in L->x
-    double *cur = (nu % 2 == 1) ? L->x.p : L->x2.p, *oth = (nu % 2 == 1) ? L->x2.p : L->x.p;
-    hipLaunchKernelGGL(k_amg_jacobi0, gr, bl, 0, c->stream, g, L->invd.p, b, cur);
-    for (int k = 1; k < nu; ++k) {
-        hipLaunchKernelGGL(k_amg_jacobi, gr, bl, 0, c->stream, g, L->op, L->invd.p, b, cur, oth);
-        std::swap(cur, oth);
-    }
-    // cur == L->x
-    hipLaunchKernelGGL(k_amg_resid, gr, bl, 0, c->stream, g, L->op, b, cur, L->r.p);
-    AmgLevel *Lc = amg->lv[l + 1];
-    hipLaunchKernelGGL(k_amg_restrict, grid_for(Lc->g.nown), bl, 0, c->stream, g, Lc->g, L->axis, L->wm.p, L->wp.p,
-                       L->r.p, Lc->b.p);
-    vcycle_rec(c, amg, l + 1, Lc->b.p, Lc->e.p);
-    hipLaunchKernelGGL(k_amg_prolong_add, gr, bl, 0, c->stream, g, Lc->g, L->axis, L->wm.p, L->wp.p, Lc->e.p, cur);
-    // post-smoothing: nu sweeps; x (caller's buffer) is distinct from L->x / L->x2, last sweep writes it
-    double *src = cur;
-    for (int k = 0; k < nu; ++k) {
-        double *dst = (k == nu - 1) ? x : (src == L->x.p ? L->x2.p : L->x.p);
-        hipLaunchKernelGGL(k_amg_jacobi, gr, bl, 0, c->stream, g, L->op, L->invd.p, b, src, dst);
-        src = dst;
-    }
 }
 
 void amg_vcycle(tp_ctx *c, Amg *amg, const double *b, double *x) {
     TP_REQUIRE(amg && !amg->lv.empty(), "AMG not set up");
     TP_REQUIRE(x != amg->lv[0]->x.p && x != amg->lv[0]->x2.p && b != x, "aliasing in amg_vcycle");
-    vcycle_rec(c, amg, 0, b, x);
+    const int nu = std::max(1, c->opt.amg_nu);
+    const int nlev = (int)amg->lv.size(), lt = amg->tail_level;
+    const dim3 bl(256);
+    std::vector<double *> xs(nlev, nullptr);       // pre-smoothed iterate of each big level
+    // down-sweep over the big levels
+    for (int l = 0; l < lt; ++l) {
+        AmgLevel *L = amg->lv[l];
+        const LevelDev Ld = dev_of(L);
+        const double *bl_ = (l == 0) ? b : L->b.p;
+        const dim3 gr = grid_for(L->g.nown);
+        double *cur = L->x.p, *oth = L->x2.p;
+        hipLaunchKernelGGL(k_amg_pre, gr, bl, 0, c->stream, Ld, bl_, nu >= 2 ? 1 : 0, cur);
+        for (int k = 2; k < nu; ++k) {
+            hipLaunchKernelGGL(k_amg_jacobi, gr, bl, 0, c->stream, Ld, bl_, cur, oth);
+            std::swap(cur, oth);
+        }
+        xs[l] = cur;
+        AmgLevel *Lc = amg->lv[l + 1];
+        if (L->g.nown >= amg->fuse_below) {
+            hipLaunchKernelGGL(k_amg_resid, gr, bl, 0, c->stream, Ld, bl_, cur, oth);
+            hipLaunchKernelGGL(k_amg_restrict, grid_for(Lc->g.nown), bl, 0, c->stream, Ld, Lc->g, oth, Lc->b.p);
+        } else {
+            hipLaunchKernelGGL(k_amg_resid_restrict, grid_for(Lc->g.nown), bl, 0, c->stream, Ld, Lc->g, bl_, cur, Lc->b.p);
+        }
+    }
+    // the tail: every level from lt down to the coarsest and back, one launch
+    {
+        AmgLevel *Lt = amg->lv[lt];
+        const double *bt = (lt == 0) ? b : Lt->b.p;
+        double *et = (lt == 0) ? x : Lt->e.p;
+        const int n = amg->ncoarse;
+        hipLaunchKernelGGL(k_amg_tail, dim3(1), dim3(1024), 0, c->stream, (const LevelDev *)amg->lvdev.p, lt, nlev, nu, n,
+                           amg->coarse_inv.p + (size_t)n * n, bt, et);
+    }
+    // up-sweep over the big levels
+    for (int l = lt - 1; l >= 0; --l) {
+        AmgLevel *L = amg->lv[l];
+        AmgLevel *Lc = amg->lv[l + 1];
+        const LevelDev Ld = dev_of(L);
+        const double *bl_ = (l == 0) ? b : L->b.p;
+        double *out = (l == 0) ? x : L->e.p;
+        const dim3 gr = grid_for(L->g.nown);
+        double *src = xs[l];
+        double *dst = (nu == 1) ? out : (src == L->x.p ? L->x2.p : L->x.p);
+        if (L->g.nown >= amg->fuse_below) {
+            hipLaunchKernelGGL(k_amg_prolong_add, gr, bl, 0, c->stream, Ld, Lc->g, Lc->e.p, src);
+            hipLaunchKernelGGL(k_amg_jacobi, gr, bl, 0, c->stream, Ld, bl_, src, dst);
+        } else {
+            hipLaunchKernelGGL(k_amg_prolong_jacobi, gr, bl, 0, c->stream, Ld, Lc->g, bl_, src, Lc->e.p, dst);
+        }
+        for (int k = 1; k < nu; ++k) {
+            src = dst;
+            dst = (k == nu - 1) ? out : (src == L->x.p ? L->x2.p : L->x.p);
+            hipLaunchKernelGGL(k_amg_jacobi, gr, bl, 0, c->stream, Ld, bl_, src, dst);
+        }
+    }
     TP_HIP(hipGetLastError());
-    c->vcycles++;
 }
 
 }  // namespace tp

@@ -51,6 +51,7 @@ tp_ctx::~tp_ctx() {
     for (auto *v : vecs) delete v;
     delete amg_p;
     delete amg_T;
+    if (pc_graph) (void)hipGraphExecDestroy(pc_graph);
     if (comm) ncclCommDestroy((ncclComm_t)comm);
     if (ev0) (void)hipEventDestroy(ev0);
     if (ev1) (void)hipEventDestroy(ev1);
@@ -144,7 +145,7 @@ int tp_destroy(tp_ctx *ctx) {
 int tp_set_options(tp_ctx *c, const tp_options *opt) {
     TP_API_BEGIN
     TP_REQUIRE(c && opt, "null argument");
-    const bool tile_changed = opt->ilu_t1 != c->opt.ilu_t1 || opt->ilu_t2 != c->opt.ilu_t2;
+    const bool tile_changed = opt->ilu_t1 != c->opt.ilu_t1 || opt->ilu_t2 != c->opt.ilu_t2 || opt->ilu_t0 != c->opt.ilu_t0;
     const bool amg_changed = opt->amg_min_cells != c->opt.amg_min_cells || opt->pc_kind != c->opt.pc_kind;
     c->opt = *opt;
     if (tile_changed) c->ilu.slots = 0;

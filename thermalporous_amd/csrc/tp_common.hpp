@@ -102,12 +102,16 @@ struct Amg {
     std::vector<AmgLevel *> lv;
     DBuf<double> coarse_inv;   // dense inverse on the coarsest grid
     int ncoarse = 0;
+    int tail_level = 0;        // first level handled by the single-workgroup tail kernel
+    long fuse_below = 200000;  // levels with fewer cells use the fused (launch-saving) kernels
+    DBuf<char> lvdev;          // device array of level descriptors (LevelDev) for the tail kernel
+    std::vector<char> lvhost;
     std::vector<int> sched;
     ~Amg() { for (auto *l : lv) delete l; }
 };
 
 struct IluData {
-    int t1 = 8, t2 = 8, nt1 = 0, nt2 = 0, ntiles = 0, nsteps = 0;
+    int t0 = 0, t1 = 8, t2 = 8, nt0 = 0, nt1 = 0, nt2 = 0, ntiles = 0, nsteps = 0;
     DBuf<double> fwd, bwd, ytmp;   // streaming factor data in consumption order
     long slots = 0;                // ntiles*nsteps*64
 };
@@ -147,6 +151,11 @@ struct tp_ctx {
     std::vector<double> hostbuf;
     // scratch vectors for PC apply
     tp::DBuf<double> w1, w2, w3, w4, dx;
+    // captured preconditioner application (hipGraph on fixed staging buffers)
+    tp::DBuf<double> pc_in, pc_out;
+    hipGraphExec_t pc_graph = nullptr;
+    uint64_t graph_epoch = 1, pc_graph_epoch = 0;
+    uintptr_t pc_sig = 0;
     // comm
     ncclComm *comm = nullptr;
     long vcycles = 0;

@@ -6,18 +6,20 @@
 // MI355X design.  On a 7-point stencil ILU(0) in natural order never updates an off-diagonal block
 // (the lower neighbours of a cell are not adjacent to one another), so
 //     M = (D~ + L_A) D~^-1 (D~ + U_A),   D~_c = A_cc - sum_{m lower} A_cm D~_m^-1 A_mc .
-// A tile is the full axis-0 line times t1 x t2 cells (t1*t2 <= 64) and is swept by ONE 64-lane
-// wavefront: lane <-> (i1,i2) inside the tile, step s <-> i0 = s - i1 - i2.  The three lower
+// A tile is t0 x t1 x t2 cells (t1*t2 <= 64; t0 = whole axis-0 line by default) and is swept by ONE
+// 64-lane wavefront: lane <-> (i1,i2) inside the tile, step s <-> i0 = s - i1 - i2.  The three lower
 // neighbours of a cell were all produced in the previous step -- by the same lane (axis 0), by lane-1
-// (axis 1) and by lane-t1 (axis 2) -- so the recurrence runs entirely in registers with two DPP
-// shuffles per step: no LDS, no barriers, no inter-workgroup flags.  Couplings that leave the tile
-// are dropped (= one bjacobi block per tile).
+// (axis 1) and by lane-t1 (axis 2) -- so the recurrence runs entirely in registers with two
+// cross-lane shuffles per step: no LDS, no barriers, no inter-workgroup flags.  Couplings that leave
+// the tile are dropped (= one bjacobi block per tile).
 //
-// The factor is stored in CONSUMPTION ORDER, [entry][tile][step][lane], with the products the
-// sweeps need premultiplied (B_cm = A_cm D~_m^-1 for the forward sweep, C_cm = D~_c^-1 A_cm and
-// D~_c^-1 for the backward sweep): every load of the sweeps is a 512-byte fully coalesced
-// wave access and each factor byte is read exactly once per application.  HBM-bound:
-// (3+4) b^2 + ... doubles per cell, the same traffic as one block SpMV.
+// The factor is stored in CONSUMPTION ORDER: one contiguous chunk per (tile, step) holding the
+// premultiplied blocks the sweep needs at that step (B_cm = A_cm D~_m^-1 forward; C_cm = D~_c^-1 A_cm
+// and D~_c^-1 backward) as [entry pair][lane][2] doubles, so that every load of the sweeps is a
+// 16-byte-per-lane, 1-KiB-per-wave fully coalesced access, each wave streams its own contiguous
+// region of HBM front to back (then back to front), and each factor byte is read exactly once per
+// application.  The chunk of step s+1 is prefetched into registers while step s computes.
+// HBM-bound: (3+4) b^2 doubles per cell plus vectors, the traffic of one block SpMV.
 #include "tp_common.hpp"
 
 namespace tp {
@@ -52,30 +54,51 @@ __device__ __forceinline__ void inv_block<3>(const double (&A)[3][3], double (&I
 
 struct IluGeom {
     GridDev g;
-    int t1, t2, nt1, nt2, nsteps;
-    long slots;          // ntiles*nsteps*64
+    int t0, t1, t2, nt0, nt1, nt2, nsteps;
+};
+
+// number of double2 pairs per chunk
+template <int B> struct IluLayout {
+    static constexpr int NEF = 3 * B * B;                 // forward entries per cell
+    static constexpr int NEB = 4 * B * B;                 // backward entries per cell
+    static constexpr int PF = (NEF + 1) / 2;              // double2 pairs per forward chunk
+    static constexpr int PB = (NEB + 1) / 2;
+    static constexpr int PY = (B + 1) / 2;                // pairs of the intermediate vector y
 };
 
 // tile/lane/step -> cell; returns false if the lane has no cell at this step
-__device__ __forceinline__ bool tile_cell(const IluGeom &G, int tile, int lane, int s, int &i0, int &j, int &k,
-                                          int &tj, int &tk, long &c) {
-    const int T1 = tile % G.nt1, T2 = tile / G.nt1;
-    j = lane % G.t1;
-    k = lane / G.t1;
-    tj = min(G.t1, G.g.n1 - T1 * G.t1);
-    tk = min(G.t2, G.g.n2 - T2 * G.t2);
-    i0 = s - j - k;
-    const bool ok = (k < G.t2) && (j < tj) && (k < tk) && (i0 >= 0) && (i0 < G.g.n0);
-    const int i1 = T1 * G.t1 + j, i2 = T2 * G.t2 + k;
-    c = G.g.np + (long)i0 + (long)G.g.n0 * i1 + G.g.np * i2;
+struct TileInfo {
+    int base0, base1, base2;   // first cell of the tile
+    int tt0, tj, tk;           // actual tile extents
+    int j, k;                  // lane coordinates
+};
+
+__device__ __forceinline__ TileInfo tile_info(const IluGeom &G, int tile, int lane) {
+    TileInfo t;
+    const int T0 = tile % G.nt0, T1 = (tile / G.nt0) % G.nt1, T2 = tile / (G.nt0 * G.nt1);
+    t.base0 = T0 * G.t0; t.base1 = T1 * G.t1; t.base2 = T2 * G.t2;
+    t.tt0 = min(G.t0, G.g.n0 - t.base0);
+    t.tj = min(G.t1, G.g.n1 - t.base1);
+    t.tk = min(G.t2, G.g.n2 - t.base2);
+    t.j = lane % G.t1;
+    t.k = lane / G.t1;
+    return t;
+}
+
+__device__ __forceinline__ bool tile_cell(const IluGeom &G, const TileInfo &t, int s, int &l0, long &c) {
+    l0 = s - t.j - t.k;
+    const bool ok = (t.k < G.t2) && (t.j < t.tj) && (t.k < t.tk) && (l0 >= 0) && (l0 < t.tt0);
+    c = G.g.np + (long)(t.base0 + l0) + (long)G.g.n0 * (t.base1 + t.j) + G.g.np * (t.base2 + t.k);
     return ok;
 }
 
 template <int B>
 __global__ __launch_bounds__(64) void k_ilu_factor(IluGeom G, const double *__restrict__ J, double *fwd,
                                                    double *bwd) {
+    using L = IluLayout<B>;
     const int tile = blockIdx.x, lane = threadIdx.x;
     const long nt = G.g.ntot;
+    const TileInfo ti = tile_info(G, tile, lane);
     double Dp[B][B];                       // D~^-1 of this lane's previous cell (axis-0 lower neighbour)
 #pragma unroll
     for (int r = 0; r < B; ++r)
@@ -83,9 +106,9 @@ __global__ __launch_bounds__(64) void k_ilu_factor(IluGeom G, const double *__re
         for (int q = 0; q < B; ++q) Dp[r][q] = 0.0;
     const long stride[3] = {1, (long)G.g.n0, G.g.np};
     for (int s = 0; s < G.nsteps; ++s) {
-        int i0, j, k, tj, tk;
+        int l0;
         long c;
-        const bool ok = tile_cell(G, tile, lane, s, i0, j, k, tj, tk, c);
+        const bool ok = tile_cell(G, ti, s, l0, c);
         // D~^-1 of the three lower neighbours (previous step): self, lane-1, lane-t1
         double Dn[3][B][B];
 #pragma unroll
@@ -96,9 +119,10 @@ __global__ __launch_bounds__(64) void k_ilu_factor(IluGeom G, const double *__re
                 Dn[1][r][q] = __shfl_up(Dp[r][q], 1, 64);
                 Dn[2][r][q] = __shfl_up(Dp[r][q], G.t1, 64);
             }
-        const bool has[3] = {ok && i0 > 0, ok && j > 0, ok && k > 0};
+        const bool has[3] = {ok && l0 > 0, ok && ti.j > 0, ok && ti.k > 0};
         double D[B][B], Di[B][B];
-        const long slot_base = ((long)tile * G.nsteps + s) * 64 + lane;
+        double *fch = fwd + ((long)tile * G.nsteps + s) * (L::PF * 128);
+        double *bch = bwd + ((long)tile * G.nsteps + s) * (L::PB * 128);
         if (ok) {
 #pragma unroll
             for (int r = 0; r < B; ++r)
@@ -144,8 +168,12 @@ __global__ __launch_bounds__(64) void k_ilu_factor(IluGeom G, const double *__re
 #pragma unroll
             for (int r = 0; r < B; ++r)
 #pragma unroll
-                for (int q = 0; q < B; ++q) fwd[(long)((a * B + r) * B + q) * G.slots + slot_base] = Bm[r][q];
+                for (int q = 0; q < B; ++q) {
+                    const int e = (a * B + r) * B + q;
+                    fch[(e >> 1) * 128 + lane * 2 + (e & 1)] = Bm[r][q];
+                }
         }
+        if (L::NEF & 1) fch[(L::NEF >> 1) * 128 + lane * 2 + 1] = 0.0;    // padding half of the last pair
         if (ok) {
             inv_block<B>(D, Di);
         } else {
@@ -154,12 +182,8 @@ __global__ __launch_bounds__(64) void k_ilu_factor(IluGeom G, const double *__re
 #pragma unroll
                 for (int q = 0; q < B; ++q) Di[r][q] = 0.0;
         }
-        // backward-sweep data: D~_c^-1 and C_cm = D~_c^-1 A_cm for the three upper neighbours in the tile
-#pragma unroll
-        for (int r = 0; r < B; ++r)
-#pragma unroll
-            for (int q = 0; q < B; ++q) bwd[(long)((3 * B + r) * B + q) * G.slots + slot_base] = Di[r][q];
-        const bool hasu[3] = {ok && i0 < G.g.n0 - 1, ok && j < tj - 1, ok && k < tk - 1};
+        // backward-sweep data: C_cm = D~_c^-1 A_cm for the three upper neighbours in the tile, then D~_c^-1
+        const bool hasu[3] = {ok && l0 < ti.tt0 - 1, ok && ti.j < ti.tj - 1, ok && ti.k < ti.tk - 1};
 #pragma unroll
         for (int a = 0; a < 3; ++a) {
             double Cm[B][B];
@@ -181,93 +205,155 @@ __global__ __launch_bounds__(64) void k_ilu_factor(IluGeom G, const double *__re
 #pragma unroll
             for (int r = 0; r < B; ++r)
 #pragma unroll
-                for (int q = 0; q < B; ++q) bwd[(long)((a * B + r) * B + q) * G.slots + slot_base] = Cm[r][q];
+                for (int q = 0; q < B; ++q) {
+                    const int e = (a * B + r) * B + q;
+                    bch[(e >> 1) * 128 + lane * 2 + (e & 1)] = Cm[r][q];
+                }
         }
 #pragma unroll
         for (int r = 0; r < B; ++r)
 #pragma unroll
-            for (int q = 0; q < B; ++q) Dp[r][q] = Di[r][q];
+            for (int q = 0; q < B; ++q) {
+                const int e = (3 * B + r) * B + q;
+                bch[(e >> 1) * 128 + lane * 2 + (e & 1)] = Di[r][q];
+                Dp[r][q] = Di[r][q];
+            }
     }
+}
+
+// one chunk = NP double2 per lane, coalesced
+template <int NP>
+__device__ __forceinline__ void load_chunk(const double *__restrict__ ch, int lane, double2 (&v)[NP]) {
+    const double2 *p = reinterpret_cast<const double2 *>(ch) + lane;
+#pragma unroll
+    for (int i = 0; i < NP; ++i) v[i] = p[i * 64];
+}
+template <int NP>
+__device__ __forceinline__ double chunk_get(const double2 (&v)[NP], int e) {
+    return (e & 1) ? v[e >> 1].y : v[e >> 1].x;
 }
 
 // x = addto + M^-1 r  (forward then backward sweep of one tile by one wavefront)
 template <int B>
 __global__ __launch_bounds__(64) void k_ilu_solve(IluGeom G, const double *__restrict__ fwd,
                                                   const double *__restrict__ bwd, const double *__restrict__ rhs,
-                                                  double *__restrict__ ytmp, double *x,
-                                                  const double *addto) {
+                                                  double *__restrict__ ytmp, double *x, const double *addto) {
+    using L = IluLayout<B>;
     const int tile = blockIdx.x, lane = threadIdx.x;
     const long nt = G.g.ntot;
+    const TileInfo ti = tile_info(G, tile, lane);
+    const long chunk0 = (long)tile * G.nsteps;
     double yp[B];
 #pragma unroll
     for (int r = 0; r < B; ++r) yp[r] = 0.0;
     // ---- forward: y_c = r_c - sum_lower B_cm y_m -------------------------------------------------
-    for (int s = 0; s < G.nsteps; ++s) {
-        int i0, j, k, tj, tk;
+    {
+        double2 nxt[L::PF];
+        double rn[B];
+        int l0;
         long c;
-        const bool ok = tile_cell(G, tile, lane, s, i0, j, k, tj, tk, c);
-        const long sb = ((long)tile * G.nsteps + s) * 64 + lane;
-        double yn[3][B];
+        bool okn = tile_cell(G, ti, 0, l0, c);
+        load_chunk<L::PF>(fwd + chunk0 * (L::PF * 128), lane, nxt);
 #pragma unroll
-        for (int r = 0; r < B; ++r) {
-            yn[0][r] = yp[r];
-            yn[1][r] = __shfl_up(yp[r], 1, 64);
-            yn[2][r] = __shfl_up(yp[r], G.t1, 64);
-        }
-        double y[B];
+        for (int r = 0; r < B; ++r) rn[r] = okn ? rhs[(long)r * nt + c] : 0.0;
+        for (int s = 0; s < G.nsteps; ++s) {
+            double2 cur[L::PF];
+            double y[B];
+            const bool ok = okn;
 #pragma unroll
-        for (int r = 0; r < B; ++r) y[r] = ok ? rhs[(long)r * nt + c] : 0.0;
-        // B_cm is stored as zero where the neighbour is outside the tile, so no branches here
+            for (int i = 0; i < L::PF; ++i) cur[i] = nxt[i];
 #pragma unroll
-        for (int a = 0; a < 3; ++a)
+            for (int r = 0; r < B; ++r) y[r] = rn[r];
+            if (s + 1 < G.nsteps) {                    // prefetch the next step while this one computes
+                okn = tile_cell(G, ti, s + 1, l0, c);
+                load_chunk<L::PF>(fwd + (chunk0 + s + 1) * (L::PF * 128), lane, nxt);
 #pragma unroll
-            for (int r = 0; r < B; ++r)
+                for (int r = 0; r < B; ++r) rn[r] = okn ? rhs[(long)r * nt + c] : 0.0;
+            }
+            double yn[3][B];
 #pragma unroll
-                for (int q = 0; q < B; ++q) y[r] -= fwd[(long)((a * B + r) * B + q) * G.slots + sb] * yn[a][q];
+            for (int r = 0; r < B; ++r) {
+                yn[0][r] = yp[r];
+                yn[1][r] = __shfl_up(yp[r], 1, 64);
+                yn[2][r] = __shfl_up(yp[r], G.t1, 64);
+            }
+            // B_cm is stored as zero where the neighbour is outside the tile, so no branches here
 #pragma unroll
-        for (int r = 0; r < B; ++r) {
-            y[r] = ok ? y[r] : 0.0;
-            ytmp[(long)r * G.slots + sb] = y[r];
-            yp[r] = y[r];
+            for (int a = 0; a < 3; ++a)
+#pragma unroll
+                for (int r = 0; r < B; ++r)
+#pragma unroll
+                    for (int q = 0; q < B; ++q) y[r] -= chunk_get<L::PF>(cur, (a * B + r) * B + q) * yn[a][q];
+            double *ych = ytmp + (chunk0 + s) * (L::PY * 128);
+#pragma unroll
+            for (int r = 0; r < B; ++r) {
+                y[r] = ok ? y[r] : 0.0;
+                ych[(r >> 1) * 128 + lane * 2 + (r & 1)] = y[r];
+                yp[r] = y[r];
+            }
         }
     }
     // ---- backward: x_c = D~_c^-1 y_c - sum_upper C_cm x_m -----------------------------------------
-    double xp[B];
+    {
+        double xp[B];
 #pragma unroll
-    for (int r = 0; r < B; ++r) xp[r] = 0.0;
-    for (int s = G.nsteps - 1; s >= 0; --s) {
-        int i0, j, k, tj, tk;
+        for (int r = 0; r < B; ++r) xp[r] = 0.0;
+        double2 nxt[L::PB], ynxt[L::PY];
+        double an[B];
+        int l0;
         long c;
-        const bool ok = tile_cell(G, tile, lane, s, i0, j, k, tj, tk, c);
-        const long sb = ((long)tile * G.nsteps + s) * 64 + lane;
-        double xn[3][B];
+        bool okn = tile_cell(G, ti, G.nsteps - 1, l0, c);
+        long cn = c;
+        load_chunk<L::PB>(bwd + (chunk0 + G.nsteps - 1) * (L::PB * 128), lane, nxt);
+        load_chunk<L::PY>(ytmp + (chunk0 + G.nsteps - 1) * (L::PY * 128), lane, ynxt);
 #pragma unroll
-        for (int r = 0; r < B; ++r) {
-            xn[0][r] = xp[r];
-            xn[1][r] = __shfl_down(xp[r], 1, 64);
-            xn[2][r] = __shfl_down(xp[r], G.t1, 64);
-        }
-        double y[B], xv[B];
+        for (int r = 0; r < B; ++r) an[r] = (okn && addto) ? addto[(long)r * nt + c] : 0.0;
+        for (int s = G.nsteps - 1; s >= 0; --s) {
+            double2 cur[L::PB], ycur[L::PY];
+            double av[B];
+            const bool ok = okn;
+            const long cc = cn;
 #pragma unroll
-        for (int r = 0; r < B; ++r) y[r] = ytmp[(long)r * G.slots + sb];
+            for (int i = 0; i < L::PB; ++i) cur[i] = nxt[i];
 #pragma unroll
-        for (int r = 0; r < B; ++r) {
-            double v = 0.0;
+            for (int i = 0; i < L::PY; ++i) ycur[i] = ynxt[i];
 #pragma unroll
-            for (int q = 0; q < B; ++q) v += bwd[(long)((3 * B + r) * B + q) * G.slots + sb] * y[q];
-            xv[r] = v;
-        }
+            for (int r = 0; r < B; ++r) av[r] = an[r];
+            if (s > 0) {
+                okn = tile_cell(G, ti, s - 1, l0, c);
+                cn = c;
+                load_chunk<L::PB>(bwd + (chunk0 + s - 1) * (L::PB * 128), lane, nxt);
+                load_chunk<L::PY>(ytmp + (chunk0 + s - 1) * (L::PY * 128), lane, ynxt);
 #pragma unroll
-        for (int a = 0; a < 3; ++a)
+                for (int r = 0; r < B; ++r) an[r] = (okn && addto) ? addto[(long)r * nt + c] : 0.0;
+            }
+            double xn[3][B];
 #pragma unroll
-            for (int r = 0; r < B; ++r)
+            for (int r = 0; r < B; ++r) {
+                xn[0][r] = xp[r];
+                xn[1][r] = __shfl_down(xp[r], 1, 64);
+                xn[2][r] = __shfl_down(xp[r], G.t1, 64);
+            }
+            double xv[B];
 #pragma unroll
-                for (int q = 0; q < B; ++q) xv[r] -= bwd[(long)((a * B + r) * B + q) * G.slots + sb] * xn[a][q];
+            for (int r = 0; r < B; ++r) {
+                double v = 0.0;
 #pragma unroll
-        for (int r = 0; r < B; ++r) {
-            xv[r] = ok ? xv[r] : 0.0;
-            xp[r] = xv[r];
-            if (ok) x[(long)r * nt + c] = (addto ? addto[(long)r * nt + c] : 0.0) + xv[r];
+                for (int q = 0; q < B; ++q) v += chunk_get<L::PB>(cur, (3 * B + r) * B + q) * chunk_get<L::PY>(ycur, q);
+                xv[r] = v;
+            }
+#pragma unroll
+            for (int a = 0; a < 3; ++a)
+#pragma unroll
+                for (int r = 0; r < B; ++r)
+#pragma unroll
+                    for (int q = 0; q < B; ++q) xv[r] -= chunk_get<L::PB>(cur, (a * B + r) * B + q) * xn[a][q];
+#pragma unroll
+            for (int r = 0; r < B; ++r) {
+                xv[r] = ok ? xv[r] : 0.0;
+                xp[r] = xv[r];
+                if (ok) x[(long)r * nt + cc] = av[r] + xv[r];
+            }
         }
     }
 }
@@ -275,30 +361,41 @@ __global__ __launch_bounds__(64) void k_ilu_solve(IluGeom G, const double *__res
 static IluGeom geom_of(const tp_ctx *c) {
     IluGeom G;
     G.g = c->g;
-    G.t1 = c->ilu.t1; G.t2 = c->ilu.t2; G.nt1 = c->ilu.nt1; G.nt2 = c->ilu.nt2;
-    G.nsteps = c->ilu.nsteps; G.slots = c->ilu.slots;
+    G.t0 = c->ilu.t0; G.t1 = c->ilu.t1; G.t2 = c->ilu.t2;
+    G.nt0 = c->ilu.nt0; G.nt1 = c->ilu.nt1; G.nt2 = c->ilu.nt2;
+    G.nsteps = c->ilu.nsteps;
     return G;
+}
+
+template <int B>
+static void alloc_factor(IluData &d) {
+    using L = IluLayout<B>;
+    const size_t chunks = (size_t)d.ntiles * d.nsteps;
+    d.fwd.alloc(chunks * L::PF * 128);
+    d.bwd.alloc(chunks * L::PB * 128);
+    d.ytmp.alloc(chunks * L::PY * 128);
 }
 
 void ilu_setup(tp_ctx *c) {
     IluData &d = c->ilu;
     const GridDev &g = c->g;
-    int t1 = c->opt.ilu_t1, t2 = c->opt.ilu_t2;
+    int t0 = c->opt.ilu_t0, t1 = c->opt.ilu_t1, t2 = c->opt.ilu_t2;
+    if (t0 <= 0) t0 = g.n0;
     if (t1 <= 0) t1 = (g.n2 == 1) ? 64 : 8;
     if (t2 <= 0) t2 = (g.n2 == 1) ? 1 : 8;
+    t0 = std::min(t0, g.n0);
     t1 = std::min(t1, g.n1);
     t2 = std::min(t2, g.n2);
-    TP_REQUIRE(t1 >= 1 && t2 >= 1 && t1 * t2 <= 64, "ILU tile must satisfy t1*t2 <= 64 (one wavefront per tile)");
-    d.t1 = t1; d.t2 = t2;
+    TP_REQUIRE(t0 >= 1 && t1 >= 1 && t2 >= 1 && t1 * t2 <= 64,
+               "ILU tile must satisfy t1*t2 <= 64 (one wavefront per tile)");
+    d.t0 = t0; d.t1 = t1; d.t2 = t2;
+    d.nt0 = (g.n0 + t0 - 1) / t0;
     d.nt1 = (g.n1 + t1 - 1) / t1;
     d.nt2 = (g.n2 + t2 - 1) / t2;
-    d.ntiles = d.nt1 * d.nt2;
-    d.nsteps = g.n0 + t1 + t2 - 2;
+    d.ntiles = d.nt0 * d.nt1 * d.nt2;
+    d.nsteps = t0 + t1 + t2 - 2;
     d.slots = (long)d.ntiles * d.nsteps * 64;
-    const int B = c->b;
-    d.fwd.alloc((size_t)3 * B * B * d.slots);
-    d.bwd.alloc((size_t)4 * B * B * d.slots);
-    d.ytmp.alloc((size_t)B * d.slots);
+    if (c->b == 3) alloc_factor<3>(d); else alloc_factor<2>(d);
 }
 
 void ilu_factor(tp_ctx *c) {

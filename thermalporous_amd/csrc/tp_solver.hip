@@ -12,6 +12,7 @@
 #include "tp_common.hpp"
 #include <cmath>
 #include <algorithm>
+#include <cstdlib>
 
 namespace tp {
 
@@ -68,6 +69,15 @@ void pc_setup(tp_ctx *c) {
     // stage 2: numeric block-ILU(0) of every tile
     ilu_factor(c);
     c->pc_ready = true;
+    // the captured pc_apply graph bakes in buffer addresses and options: invalidate it when any changes
+    const uintptr_t sig[] = {(uintptr_t)c->opA00.base, (uintptr_t)c->opA01.base, (uintptr_t)c->opA10.base,
+                             (uintptr_t)c->Sm.p, (uintptr_t)c->ilu.fwd.p, (uintptr_t)c->amg_p, (uintptr_t)c->amg_T,
+                             (uintptr_t)c->w1.p, (uintptr_t)c->w3.p, (uintptr_t)c->w4.p, (uintptr_t)c->dcoef.p,
+                             (uintptr_t)c->opt.amg_nu, (uintptr_t)c->opt.pc_kind, (uintptr_t)c->opt.decoup,
+                             (uintptr_t)c->ilu.ntiles, (uintptr_t)c->ilu.nsteps};
+    uintptr_t h = 1469598103934665603ull;
+    for (uintptr_t v : sig) h = (h ^ v) * 1099511628211ull;
+    if (h != c->pc_sig) { c->pc_sig = h; c->graph_epoch++; }
 }
 
 // y = B1 x :  CPRStage1PC.apply (preconditioners.py:881-903) / CPTRStage1PC.apply (:1550-1567)
@@ -96,13 +106,47 @@ void stage1_apply(tp_ctx *c, const double *x, double *y) {
 }
 
 // composite multiplicative: y = B1 x ; r = x - J y ; y += B2 r
-void pc_apply(tp_ctx *c, const double *x, double *y) {
-    TP_REQUIRE(c->pc_ready, "pc_apply before pc_setup");
+static void pc_apply_body(tp_ctx *c, const double *x, double *y) {
     const int npri = c->opt.pc_kind == 1 ? 2 : 1;
     stage1_apply(c, x, y);
     if (c->comm) halo_exchange(c, c->g, y, npri, c->g.ntot);
     resid_block_cols(c, c->J.p, x, y, npri, c->w1.p);        // secondary fields of y are zero
     ilu_solve(c, c->w1.p, y, y);                             // y = y + M^-1 r
+}
+
+// One preconditioner application is ~100 short kernels (the V-cycles' coarse levels); issued eagerly
+// the host launch path (~3 us per kernel) is slower than the GPU executes them.  The whole sequence
+// is therefore captured ONCE into a hipGraph on fixed staging buffers and replayed per Krylov
+// iteration (two extra vector copies, ~20 us, buy back ~300 us of launch latency).
+void pc_apply(tp_ctx *c, const double *x, double *y) {
+    TP_REQUIRE(c->pc_ready, "pc_apply before pc_setup");
+    static const bool use_graph = !(getenv("TP_GRAPH") && atoi(getenv("TP_GRAPH")) == 0);
+    c->vcycles += c->opt.pc_kind == 1 ? 3 : 1;
+    if (!use_graph || c->comm) {
+        pc_apply_body(c, x, y);
+        return;
+    }
+    const long nv = (long)c->b * c->g.ntot;
+    if (c->pc_in.n < (size_t)nv) { c->pc_in.alloc(nv); c->pc_out.alloc(nv); c->graph_epoch++; }
+    if (!c->pc_graph || c->pc_graph_epoch != c->graph_epoch) {
+        if (c->pc_graph) { (void)hipGraphExecDestroy(c->pc_graph); c->pc_graph = nullptr; }
+        hipGraph_t graph = nullptr;
+        TP_HIP(hipStreamBeginCapture(c->stream, hipStreamCaptureModeThreadLocal));
+        try {
+            pc_apply_body(c, c->pc_in.p, c->pc_out.p);
+        } catch (...) {
+            (void)hipStreamEndCapture(c->stream, &graph);
+            if (graph) (void)hipGraphDestroy(graph);
+            throw;
+        }
+        TP_HIP(hipStreamEndCapture(c->stream, &graph));
+        TP_HIP(hipGraphInstantiate(&c->pc_graph, graph, nullptr, nullptr, 0));
+        TP_HIP(hipGraphDestroy(graph));
+        c->pc_graph_epoch = c->graph_epoch;
+    }
+    vec_copy(c, x, c->pc_in.p, nv);
+    TP_HIP(hipGraphLaunch(c->pc_graph, c->stream));
+    vec_copy(c, c->pc_out.p, y, nv);
 }
 
 // ------------------------------------------------------------------------------------------------

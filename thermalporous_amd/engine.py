@@ -43,7 +43,7 @@ class tp_options(C.Structure):
                 ("ksp_max_it", C.c_int32), ("ksp_restart", C.c_int32), ("snes_rtol", C.c_double),
                 ("snes_atol", C.c_double), ("snes_stol", C.c_double), ("snes_max_it", C.c_int32),
                 ("amg_omega", C.c_double), ("amg_nu", C.c_int32), ("amg_min_cells", C.c_int32),
-                ("ilu_t1", C.c_int32), ("ilu_t2", C.c_int32)]
+                ("ilu_t1", C.c_int32), ("ilu_t2", C.c_int32), ("ilu_t0", C.c_int32)]
 
 
 class tp_solve_info(C.Structure):
@@ -162,7 +162,8 @@ class HipEngine:
         t = o["ilu_tile"]
         return tp_options(_PC[o["pc"]], _DECOUP[o["decoup"]], o["ksp_rtol"], o["ksp_atol"], o["ksp_max_it"],
                           o["ksp_restart"], o["snes_rtol"], o["snes_atol"], o["snes_stol"], o["snes_max_it"],
-                          o["amg_omega"], o["amg_nu"], o["amg_min_cells"], int(min(t[1], 64)), int(min(t[2], 64)))
+                          o["amg_omega"], o["amg_nu"], o["amg_min_cells"], int(min(t[1], 64)), int(min(t[2], 64)),
+                          0 if t[0] >= (1 << 30) else int(t[0]))
 
     def set_options(self, **kw):
         self.opts.update(kw)
