@@ -78,14 +78,23 @@ class TiledILU0:
     D~_c = A_cc - sum_{m lower, same tile} A_cm D~_m^-1 A_mc.  Couplings that leave the tile are
     dropped (= PETSc bjacobi with one block per tile)."""
 
-    def __init__(self, shape, tile):
+    def __init__(self, shape, tile, slabs=None):
+        """slabs: list of (lo, hi) plane ranges along axis 2 (the multi-GPU decomposition); tiles
+        restart at every slab boundary because each GPU factors only its own rows."""
         n2, n1, n0 = shape
         self.shape = shape
         t0, t1, t2 = (max(1, min(int(t), n)) for t, n in zip(tile, (n0, n1, n2)))
         self.tile = (t0, t1, t2)
         i2, i1, i0 = np.meshgrid(np.arange(n2), np.arange(n1), np.arange(n0), indexing="ij")
-        self.l = [i0 % t0, i1 % t1, i2 % t2]
-        self.tdim = [np.minimum(t, n - (i // t) * t) for t, n, i in zip((t0, t1, t2), (n0, n1, n2), (i0, i1, i2))]
+        slabs = slabs or [(0, n2)]
+        lo2 = np.zeros(n2, dtype=int)
+        hi2 = np.zeros(n2, dtype=int)
+        for lo, hi in slabs:
+            lo2[lo:hi], hi2[lo:hi] = lo, hi
+        r2 = i2 - lo2[i2]                       # plane index relative to the owning slab
+        self.l = [i0 % t0, i1 % t1, r2 % t2]
+        self.tdim = [np.minimum(t0, n0 - (i0 // t0) * t0), np.minimum(t1, n1 - (i1 // t1) * t1),
+                     np.minimum(t2, (hi2[i2] - lo2[i2]) - (r2 // t2) * t2)]
         self.level = (self.l[0] + self.l[1] + self.l[2]).reshape(-1)
         self.nlev = int(self.level.max()) + 1
         self.strides = (1, n0, n0 * n1)
@@ -340,21 +349,37 @@ def decouple(J, kind, primary):
     return At, d
 
 
+def slab_ranges(n2, nslabs):
+    """Planes [lo, hi) of internal axis 2 per slab (same rule as thermalporous_amd.engine.slab_range)."""
+    base, rem = divmod(n2, nslabs)
+    out = []
+    for r in range(nslabs):
+        lo = r * base + min(r, rem)
+        out.append((lo, lo + base + (1 if r < rem else 0)))
+    return out
+
+
 class TwoStagePC:
     """Composite multiplicative PC: y = B1 x; r = x - J y; y += B2 r (PCCOMPOSITE multiplicative,
-    singlephase.py:341-343).  B1 = CPR or CPTR stage 1, B2 = tiled block-ILU(0)."""
+    singlephase.py:341-343).  B1 = CPR or CPTR stage 1, B2 = tiled block-ILU(0).
+    opts["nslabs"] > 1 emulates the N-GPU algorithm in one process: the ILU tiles restart at every slab
+    boundary (bjacobi across ranks, twophase.py:533: each GPU factors only its own rows); stage 1 is
+    the same global operator as on one GPU (every rank runs the V-cycles on the gathered pressure system)."""
 
     def __init__(self, prob, opts):
         self.prob = prob
         self.o = opts
         n = prob.n
         shape = prob.shape
-        st = [float(np.mean(prob.TK[a])) if n[a] > 1 else 0.0 for a in range(3)]
+        self.slabs = slab_ranges(n[2], int(opts.get("nslabs", 1)))
         kw = dict(omega=opts["amg_omega"], min_cells=opts["amg_min_cells"], nu=opts["amg_nu"])
+
+        # coarsening schedule from the mean interior-face transmissibility per axis
+        st = [float(np.mean(prob.TK[a][_lo(a)])) if n[a] > 1 else 0.0 for a in range(3)]
         self.amg_p = SemiAMG(n, st, **kw)
         self.amg_T = SemiAMG(n, [prob.G[a] if n[a] > 1 else 0.0 for a in range(3)], **kw) \
             if opts["pc"] in ("cptr", "fieldsplit_cd") else None
-        self.ilu = TiledILU0(shape, opts["ilu_tile"])
+        self.ilu = TiledILU0(shape, opts["ilu_tile"], self.slabs)
         self.vcycles = 0
 
     def setup(self, J, Sm=None):

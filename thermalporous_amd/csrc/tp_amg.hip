@@ -384,15 +384,15 @@ static LevelDev dev_of(const AmgLevel *L) {
     return d;
 }
 
-void amg_build(tp_ctx *c, Amg *&amg, const double strength[3]) {
+void amg_build(tp_ctx *c, Amg *&amg, const GridDev &g0, const double strength[3]) {
     delete amg;
     amg = new Amg();
-    const int n[3] = {c->g.n0, c->g.n1, c->g.n2};
+    const int n[3] = {g0.n0, g0.n1, g0.n2};
     amg->sched = schedule(n, strength, std::max(1, c->opt.amg_min_cells));
     int m[3] = {n[0], n[1], n[2]};
     for (size_t l = 0; l <= amg->sched.size(); ++l) {
         AmgLevel *L = new AmgLevel();
-        // coarse levels are local boxes: no live halos (multi-GPU AMG is block-Jacobi per slab)
+        // every level is a box with dead halo planes (multi-GPU: the hierarchy lives on the gathered global grid)
         L->g = make_grid(m[0], m[1], m[2], m[2], 0);
         const size_t nt = (size_t)L->g.ntot;
         if (l > 0) {
@@ -422,8 +422,6 @@ void amg_build(tp_ctx *c, Amg *&amg, const double strength[3]) {
 }
 
 void amg_setup(tp_ctx *c, Amg *amg, const Stencil &A0) {
-    // level 0 works on the slab's own grid descriptor but with dead halos (couplings into other
-    // slabs are ignored inside the AMG)
     AmgLevel *L0 = amg->lv[0];
     L0->op = A0;
     for (size_t l = 0; l < amg->lv.size(); ++l) {

@@ -40,6 +40,29 @@ void halo_exchange(tp_ctx *c, const GridDev &g, double *x, int nf, long fstride)
     TP_NCCL(ncclGroupEnd());
 }
 
+void slab_of(const tp_ctx *c, int rank, int &lo, int &hi) {
+    const int base = c->grid.gn2 / c->grid.nranks, rem = c->grid.gn2 % c->grid.nranks;
+    lo = rank * base + std::min(rank, rem);
+    hi = lo + base + (rank < rem ? 1 : 0);
+}
+
+// Every rank broadcasts the owned part of each of its planes into the same place of everybody's global
+// array (uneven slabs: one ncclBroadcast per (plane, root) inside one group).
+void gather_slabs(tp_ctx *c, const double *local, long lstride, double *global, long gstride, int nplanes) {
+    TP_REQUIRE(c->comm, "gather_slabs without a communicator");
+    ncclComm_t comm = (ncclComm_t)c->comm;
+    const long np = c->g.np;
+    TP_NCCL(ncclGroupStart());
+    for (int p = 0; p < nplanes; ++p)
+        for (int r = 0; r < c->grid.nranks; ++r) {
+            int lo, hi;
+            slab_of(c, r, lo, hi);
+            TP_NCCL(ncclBroadcast(local + (long)p * lstride + np, global + (long)p * gstride + np * (lo + 1),
+                                  (size_t)np * (hi - lo), ncclDouble, r, comm, c->stream));
+        }
+    TP_NCCL(ncclGroupEnd());
+}
+
 void allreduce_sum(tp_ctx *c, double *dev, int n) {
     if (!c->comm || n <= 0) return;
     TP_NCCL(ncclAllReduce(dev, dev, n, ncclDouble, ncclSum, (ncclComm_t)c->comm, c->stream));
@@ -117,6 +140,7 @@ int tp_create(const tp_grid *grid, const tp_params *prm, const tp_options *opt, 
     c->grid = *grid; c->prm = *prm; c->opt = *opt; c->device = device;
     c->nph = grid->nphase; c->b = grid->nphase + 1;
     c->g = make_grid(grid->n0, grid->n1, grid->n2, grid->gn2, grid->off2);
+    c->gfull = make_grid(grid->n0, grid->n1, grid->gn2, grid->gn2, 0);
     c->vol = grid->h[0] * grid->h[1] * grid->h[2];
     derive_params(c);
     TP_HIP(hipStreamCreate(&c->stream));
@@ -174,6 +198,9 @@ int tp_comm_init(tp_ctx *c, const void *id128) {
     ncclComm_t comm;
     TP_NCCL(ncclCommInitRank(&comm, c->grid.nranks, id, c->grid.rank));
     c->comm = (ncclComm *)comm;
+    int lo, hi;
+    slab_of(c, c->grid.rank, lo, hi);
+    TP_REQUIRE(lo == c->grid.off2 && hi - lo == c->grid.n2, "slab of this rank does not follow the library's partition rule");
     TP_API_END
 }
 
@@ -437,6 +464,7 @@ int tp_amg_vcycle(tp_ctx *c, int32_t which, int32_t field_b, int32_t b, int32_t 
     TP_REQUIRE(c->pc_ready, "AMG not set up");
     Amg *amg = which == 0 ? c->amg_p : c->amg_T;
     TP_REQUIRE(amg, "this AMG hierarchy does not exist for the selected preconditioner");
+    TP_REQUIRE(!c->comm, "tp_amg_vcycle works on slab vectors: single-slab contexts only");
     TP_REQUIRE(field_b >= 0 && field_b < c->b && field_x >= 0 && field_x < c->b, "bad field index");
     TP_REQUIRE(!(b == x && field_b == field_x), "b and x must differ");
     amg_vcycle(c, amg, vec_of(c, b).p + (long)field_b * c->g.ntot, vec_of(c, x).p + (long)field_x * c->g.ntot);
@@ -446,6 +474,7 @@ int tp_amg_vcycle(tp_ctx *c, int32_t which, int32_t field_b, int32_t b, int32_t 
 int tp_schur_apply(tp_ctx *c, int32_t x, int32_t y) {
     TP_API_BEGIN
     TP_REQUIRE(c->pc_ready && c->amg_T, "S~ AMG not set up (pc_cptr only)");
+    TP_REQUIRE(!c->comm, "tp_schur_apply works on slab vectors: single-slab contexts only");
     TP_REQUIRE(x != y, "x and y must differ");
     amg_vcycle(c, c->amg_T, vec_of(c, x).p + c->g.ntot, vec_of(c, y).p + c->g.ntot);
     TP_API_END

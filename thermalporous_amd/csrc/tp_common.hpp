@@ -158,6 +158,9 @@ struct tp_ctx {
     uintptr_t pc_sig = 0;
     // comm
     ncclComm *comm = nullptr;
+    // multi-GPU stage 1: the pressure (and temperature) systems gathered on the global grid of every rank
+    tp::GridDev gfull;
+    tp::DBuf<double> gA00, gA01, gA10, gSm, gvec;   // operators: 7 planes each; gvec: work vectors
     long vcycles = 0;
     ~tp_ctx();
 };
@@ -192,12 +195,15 @@ void ilu_setup(tp_ctx *c);
 void ilu_factor(tp_ctx *c);
 void ilu_solve(tp_ctx *c, const double *r, double *x, const double *addto);             // x = addto + M^-1 r
 // AMG
-void amg_build(tp_ctx *c, Amg *&amg, const double strength[3]);
+void amg_build(tp_ctx *c, Amg *&amg, const GridDev &g0, const double strength[3]);
 void amg_setup(tp_ctx *c, Amg *amg, const Stencil &A0);
 void amg_vcycle(tp_ctx *c, Amg *amg, const double *b, double *x);
 // comm
 void halo_exchange(tp_ctx *c, const GridDev &g, double *x, int nf, long fstride);
 void allreduce_sum(tp_ctx *c, double *dev, int n);
+void slab_of(const tp_ctx *c, int rank, int &lo, int &hi);
+// gather `nplanes` slab-distributed cell planes into arrays on the global grid (every rank gets all slabs)
+void gather_slabs(tp_ctx *c, const double *local, long lstride, double *global, long gstride, int nplanes);
 // solver
 void pc_setup(tp_ctx *c);
 void stage1_apply(tp_ctx *c, const double *x, double *y);

@@ -22,51 +22,86 @@ static void ensure_work(tp_ctx *c) {
     if (c->w1.n < nv) { c->w1.alloc(nv); c->w2.alloc(nv); c->w3.alloc(nv); c->w4.alloc(nv); }
 }
 
+// mean interior-face transmissibility per axis over the GLOBAL grid (sum/count all-reduced over slabs)
+static void face_strengths(tp_ctx *c, double st[3]) {
+    const long nt = c->g.ntot;
+    std::vector<double> h(nt);
+    double acc[6] = {0, 0, 0, 0, 0, 0};
+    const int n[3] = {c->g.n0, c->g.n1, c->g.n2};
+    for (int a = 0; a < 3; ++a) {
+        TP_HIP(hipMemcpy(h.data(), c->TK[a].p, nt * sizeof(double), hipMemcpyDeviceToHost));
+        for (int i2 = 0; i2 < n[2]; ++i2)
+            for (int i1 = 0; i1 < n[1]; ++i1)
+                for (int i0 = 0; i0 < n[0]; ++i0) {
+                    const int idx[3] = {i0, i1, c->g.off2 + i2};
+                    const int ext[3] = {n[0], n[1], c->g.gn2};
+                    if (idx[a] >= ext[a] - 1) continue;
+                    acc[a] += h[c->g.np * (i2 + 1) + (long)c->g.n0 * i1 + i0];
+                    acc[3 + a] += 1.0;
+                }
+    }
+    if (c->comm) {
+        if (c->red_out.n < 6) c->red_out.alloc(64);
+        TP_HIP(hipMemcpyAsync(c->red_out.p, acc, sizeof(acc), hipMemcpyHostToDevice, c->stream));
+        allreduce_sum(c, c->red_out.p, 6);
+        TP_HIP(hipMemcpyAsync(acc, c->red_out.p, sizeof(acc), hipMemcpyDeviceToHost, c->stream));
+        TP_HIP(hipStreamSynchronize(c->stream));
+    }
+    for (int a = 0; a < 3; ++a) st[a] = acc[3 + a] > 0 ? acc[a] / acc[3 + a] : 0.0;
+}
+
 void pc_setup(tp_ctx *c) {
     TP_REQUIRE(c->jac_ready, "pc_setup needs an assembled Jacobian");
     ensure_work(c);
+    const bool cptr = c->opt.pc_kind == 1;
     // stage 1: decoupling + AMG hierarchies (CPRStage1PC.update / CPTRStage1PC.update)
     decouple(c);
+    // single GPU: the AMG works on the slab (= whole grid).  Multi-GPU: stage 1 is NOT decomposed -- every
+    // rank gathers the scalar stage-1 operators and runs the V-cycles on the global grid, so that the
+    // preconditioner (and the iteration counts) are those of the single-GPU run; only stage 2 is bjacobi.
+    const GridDev gam = c->comm ? c->gfull : make_grid(c->g.n0, c->g.n1, c->g.n2, c->g.n2, 0);
     if (!c->amg_p) {
-        // coarsening schedule from mean face transmissibilities (decided once; structure is static)
-        double st[3] = {0, 0, 0};
-        const long nt = c->g.ntot;
-        std::vector<double> h(nt);
-        for (int a = 0; a < 3; ++a) {
-            TP_HIP(hipMemcpy(h.data(), c->TK[a].p, nt * sizeof(double), hipMemcpyDeviceToHost));
-            double s = 0.0;
-            long cnt = 0;
-            const int n[3] = {c->g.n0, c->g.n1, c->g.n2};
-            for (int i2 = 0; i2 < n[2]; ++i2)
-                for (int i1 = 0; i1 < n[1]; ++i1)
-                    for (int i0 = 0; i0 < n[0]; ++i0) {
-                        const int idx[3] = {i0, i1, i2};
-                        if (idx[a] >= n[a] - 1) continue;
-                        s += h[c->g.np * (i2 + 1) + (long)c->g.n0 * i1 + i0];
-                        ++cnt;
-                    }
-            st[a] = cnt ? s / cnt : 0.0;
-        }
-        amg_build(c, c->amg_p, st);
-        if (c->opt.pc_kind == 1) {
+        double st[3];
+        face_strengths(c, st);         // coarsening schedule decided once; structure is static
+        amg_build(c, c->amg_p, gam, st);
+        if (cptr) {
             double sg[3];
+            const int n[3] = {gam.n0, gam.n1, gam.n2};
             for (int a = 0; a < 3; ++a) {
                 const double hh = c->grid.h[a];
-                const int n[3] = {c->g.n0, c->g.n1, c->g.n2};
                 sg[a] = n[a] > 1 ? c->vol / (hh * hh) : 0.0;
             }
-            amg_build(c, c->amg_T, sg);
+            amg_build(c, c->amg_T, gam, sg);
         }
     }
-    amg_setup(c, c->amg_p, c->opA00);
-    if (c->opt.pc_kind == 1) {
-        TP_REQUIRE(c->Sm.p, "pc_cptr needs the S~ operator (assemble with want_schur)");
-        Stencil S;
-        S.base = c->Sm.p;
-        S.slot_stride = c->g.ntot;
-        amg_setup(c, c->amg_T, S);
+    Stencil Sl;
+    Sl.base = c->Sm.p;
+    Sl.slot_stride = c->g.ntot;
+    if (cptr) TP_REQUIRE(c->Sm.p, "pc_cptr needs the S~ operator (assemble with want_schur)");
+    if (c->comm) {
+        const size_t ng = (size_t)c->gfull.ntot;
+        if (c->gA00.n < 7 * ng) {
+            c->gA00.alloc(7 * ng);
+            if (cptr) { c->gA01.alloc(7 * ng); c->gA10.alloc(7 * ng); c->gSm.alloc(7 * ng); }
+            c->gvec.alloc(6 * ng);
+        }
+        gather_slabs(c, c->opA00.base, c->opA00.slot_stride, c->gA00.p, (long)ng, 7);
+        Stencil G;
+        G.slot_stride = (long)ng;
+        G.base = c->gA00.p;
+        amg_setup(c, c->amg_p, G);
+        if (cptr) {
+            gather_slabs(c, c->opA01.base, c->opA01.slot_stride, c->gA01.p, (long)ng, 7);
+            gather_slabs(c, c->opA10.base, c->opA10.slot_stride, c->gA10.p, (long)ng, 7);
+            gather_slabs(c, Sl.base, Sl.slot_stride, c->gSm.p, (long)ng, 7);
+            G.base = c->gSm.p;
+            amg_setup(c, c->amg_T, G);
+        }
+    } else {
+        amg_setup(c, c->amg_p, c->opA00);
+        if (cptr) amg_setup(c, c->amg_T, Sl);
     }
-    // stage 2: numeric block-ILU(0) of every tile
+    // stage 2: numeric block-ILU(0) of every tile of this rank's slab
     ilu_factor(c);
     c->pc_ready = true;
     // the captured pc_apply graph bakes in buffer addresses and options: invalidate it when any changes
@@ -90,12 +125,39 @@ void stage1_apply(tp_ctx *c, const double *x, double *y) {
     const int npri = c->opt.pc_kind == 1 ? 2 : 1;
     for (int f = npri; f < c->b; ++f) vec_zero(c, y + (long)f * nt, nt);
     stage1_rhs(c, x, 0, r0);                       // r_p = x_p - (D_ps D_ss^-1) x_s
-    if (c->opt.pc_kind == 0) {
+    if (npri == 2) {
+        TP_REQUIRE(c->b == 3, "pc_cptr is a two-phase preconditioner");
+        stage1_rhs(c, x, 1, r1);
+    }
+    if (c->comm) {
+        // gathered global system: work vectors gr0, gr1, gy0, gy1, gt, gw on the global grid
+        const GridDev &G = c->gfull;
+        const long ng = G.ntot;
+        double *gr0 = c->gvec.p, *gr1 = gr0 + ng, *gy0 = gr0 + 2 * ng, *gy1 = gr0 + 3 * ng, *gt = gr0 + 4 * ng,
+               *gw = gr0 + 5 * ng;
+        gather_slabs(c, r0, nt, gr0, ng, npri);    // r0 (and r1: consecutive planes on both sides)
+        if (npri == 1) {
+            amg_vcycle(c, c->amg_p, gr0, gy0);
+        } else {
+            Stencil A10, A01;
+            A10.base = c->gA10.p; A10.slot_stride = ng;
+            A01.base = c->gA01.p; A01.slot_stride = ng;
+            amg_vcycle(c, c->amg_p, gr0, gw);
+            spmv_scalar(c, G, A10, gw, gt, -1.0, gr1);
+            amg_vcycle(c, c->amg_T, gt, gy1);
+            spmv_scalar(c, G, A01, gy1, gt, -1.0, gr0);
+            amg_vcycle(c, c->amg_p, gt, gy0);
+        }
+        // my slab of the result INCLUDING its halo planes (global planes lo-1 .. hi), so y needs no exchange
+        const long off = g.np * c->grid.off2;
+        vec_copy(c, gy0 + off, y, nt);
+        if (npri == 2) vec_copy(c, gy1 + off, y + nt, nt);
+        return;
+    }
+    if (npri == 1) {
         amg_vcycle(c, c->amg_p, r0, y);
         return;
     }
-    TP_REQUIRE(c->b == 3, "pc_cptr is a two-phase preconditioner");
-    stage1_rhs(c, x, 1, r1);
     // PCFIELDSPLIT schur FULL on (p,T) (twophase.py:536-545): K(A00), K(S~) = one V-cycle each
     double *y0 = y, *y1 = y + nt;
     amg_vcycle(c, c->amg_p, r0, c->w4.p);                                   // y0 = K(A00) r0
@@ -108,8 +170,7 @@ void stage1_apply(tp_ctx *c, const double *x, double *y) {
 // composite multiplicative: y = B1 x ; r = x - J y ; y += B2 r
 static void pc_apply_body(tp_ctx *c, const double *x, double *y) {
     const int npri = c->opt.pc_kind == 1 ? 2 : 1;
-    stage1_apply(c, x, y);
-    if (c->comm) halo_exchange(c, c->g, y, npri, c->g.ntot);
+    stage1_apply(c, x, y);       // multi-GPU: y comes back with live halo planes
     resid_block_cols(c, c->J.p, x, y, npri, c->w1.p);        // secondary fields of y are zero
     ilu_solve(c, c->w1.p, y, y);                             // y = y + M^-1 r
 }
@@ -191,7 +252,6 @@ int fgmres(tp_ctx *c, const double *bvec, double *x, int *its_out, double *rnorm
         gvec[0] = beta;
         ensure_basis(2);
         vec_scale_to(c, B, 1.0 / beta, rsrc, c->V.p);                      // v0 = r/beta
-        if (c->comm) halo_exchange(c, g, c->V.p, B, g.ntot);
         int k = 0, reason = 0;
         double res = beta;
         for (int j = 0; j < m; ++j) {
@@ -224,7 +284,6 @@ int fgmres(tp_ctx *c, const double *bvec, double *x, int *its_out, double *rnorm
             if (res <= tol) { reason = 2; break; }
             if (hn == 0.0) { reason = 2; break; }
             vec_scale_to(c, B, 1.0 / hn, w, w);                             // v_{j+1} = w/||w||
-            if (c->comm) halo_exchange(c, g, w, B, g.ntot);
         }
         // y = H^-1 g ; x += Z y
         yk.assign(k, 0.0);
