@@ -1,0 +1,14 @@
+"""Runs each hot kernel of the C4 workload a few times (for rocprofv3 --pmc passes / kernel traces)."""
+import sys, os
+sys.path.insert(0, os.path.join(os.path.dirname(os.path.abspath(__file__)), ".."))
+import bench
+m = bench.make_model("c4")
+m.start()
+for _ in range(3):
+    m.step()
+e = m.engine
+e.lib.tp_jacobian(e.ctx)
+e.pc_setup()
+for w in range(5):
+    e.time_kernel(w, 5)
+print("done")
