@@ -75,6 +75,8 @@ typedef struct tp_options {
     int32_t amg_min_cells;   /* coarsest-grid size (dense solve) */
     int32_t ilu_t1, ilu_t2;  /* bjacobi tile extent along axes 1,2 (t1*t2 <= 64: one wavefront per tile) */
     int32_t ilu_t0;          /* tile extent along axis 0 (<= 0: the whole line) */
+    int32_t amg_full_levels; /* V(nu,nu) on the first amg_full_levels levels ... */
+    int32_t amg_coarse_pre, amg_coarse_post;  /* ... V(coarse_pre, coarse_post) below (coarse_post >= 1) */
 } tp_options;
 
 /* Result of one nonlinear solve (SNES iteration number / linear iterations / reason:

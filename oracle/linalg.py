@@ -184,9 +184,15 @@ class SemiAMG:
     term are kept and every level stays a 7-point stencil.  V(nu,nu) cycle, damped Jacobi.
     """
 
-    def __init__(self, n, strength, omega=0.8, min_cells=64, nu=1, max_levels=40):
+    def __init__(self, n, strength, omega=0.8, min_cells=64, nu=1, max_levels=40, full_levels=99, coarse_pre=None,
+                 coarse_post=None):
+        """V(nu,nu) on the first `full_levels` levels, V(coarse_pre, coarse_post) below (the coarse levels of
+        the GPU cycle are launch-latency bound: dropping their pre-smoothing costs no Krylov iterations)."""
         self.n = tuple(n)
         self.omega, self.nu = omega, nu
+        self.full_levels = full_levels
+        self.coarse_pre = nu if coarse_pre is None else coarse_pre
+        self.coarse_post = nu if coarse_post is None else coarse_post
         self.sched = self._schedule(n, strength, min_cells, max_levels)
 
     @staticmethod
@@ -298,13 +304,17 @@ class SemiAMG:
             if self.coarse is None:
                 return b / self.coarse_scalar
             return self.coarse.solve(b.reshape(-1)).reshape(b.shape)
-        x = self.omega * b / A[0]
-        for _ in range(self.nu - 1):
-            x = self._smooth(A, b, x)
-        r = b - spmv_scalar(A, x)
+        pre, post = (self.nu, self.nu) if lvl < self.full_levels else (self.coarse_pre, self.coarse_post)
+        if pre == 0:
+            x, r = np.zeros_like(b), b
+        else:
+            x = self.omega * b / A[0]
+            for _ in range(pre - 1):
+                x = self._smooth(A, b, x)
+            r = b - spmv_scalar(A, x)
         ec = self.vcycle(self.restrict(r, lvl), lvl + 1)
         x = x + self.prolong(ec, lvl, b.shape)
-        for _ in range(self.nu):
+        for _ in range(post):
             x = self._smooth(A, b, x)
         return x
 
@@ -372,7 +382,9 @@ class TwoStagePC:
         n = prob.n
         shape = prob.shape
         self.slabs = slab_ranges(n[2], int(opts.get("nslabs", 1)))
-        kw = dict(omega=opts["amg_omega"], min_cells=opts["amg_min_cells"], nu=opts["amg_nu"])
+        kw = dict(omega=opts["amg_omega"], min_cells=opts["amg_min_cells"], nu=opts["amg_nu"],
+                  full_levels=opts.get("amg_full_levels", 99), coarse_pre=opts.get("amg_coarse_pre"),
+                  coarse_post=opts.get("amg_coarse_post"))
 
         # coarsening schedule from the mean interior-face transmissibility per axis
         st = [float(np.mean(prob.TK[a][_lo(a)])) if n[a] > 1 else 0.0 for a in range(3)]

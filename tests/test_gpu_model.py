@@ -1,0 +1,119 @@
+"""GPU tests at the model level (SinglePhase/TwoPhase/PC classes through the C ABI) and size-independent
+properties at BASELINE config 4's full size."""
+import numpy as np
+import pytest
+
+import cases
+
+pytestmark = pytest.mark.gpu
+
+
+def rel2(a, b):
+    return np.linalg.norm((a - b).ravel())/max(np.linalg.norm(b.ravel()), 1e-300)
+
+
+def test_time_loop_parity_config1():
+    """BASELINE config 1 end to end (tests/test_homo_wells.py of the reference: 2 steps, const-rate wells,
+    pc_cpr) through the SinglePhase/ThermalModel API: HIP engine vs oracle engine."""
+    from oracle.engine import OracleEngine
+    from thermalporous_amd.singlephase import SinglePhase
+    res = []
+    for factory in (OracleEngine, None):
+        spec, u0, p, g, c = cases.c1_homogeneous(N=20)
+        m = SinglePhase(g, c, p, end=2.0, maxdt=1.0, small_dt_start=False, solver_parameters="pc_cpr",
+                        filename=None, verbosity=False, _engine_factory=factory)
+        m.solve()
+        res.append((m.nits_vec, m.lits_vec, m.u.dat.data_ro[0].copy(), m.u.dat.data_ro[1].copy()))
+    assert res[0][0] == res[1][0]
+    assert all(abs(a - b) <= 1 for a, b in zip(res[0][1], res[1][1]))
+    assert rel2(res[1][2], res[0][2]) < 1e-8 and rel2(res[1][3], res[0][3]) < 1e-8
+
+
+def test_time_loop_parity_two_phase_2d():
+    """BASELINE config 3 (reduced): two-phase 2-D SPE10-like layer, Peaceman wells, pc_cptr, adaptive dt."""
+    from oracle.engine import OracleEngine
+    from thermalporous_amd.twophase import TwoPhase
+    res = []
+    for factory in (OracleEngine, None):
+        spec, u0, p, g, c = cases.c3_spe10_2d(16, 22, 2)
+        m = TwoPhase(g, c, p, end=0.004, maxdt=0.002, solver_parameters="pc_cptr", filename=None, verbosity=False,
+                     _engine_factory=factory)
+        m.solve()
+        res.append((m.nits_vec, m.lits_vec, m.dt_vec, [m.u.dat.data_ro[f].copy() for f in range(3)]))
+    assert res[0][0] == res[1][0] and np.allclose(res[0][2], res[1][2])
+    assert sum(abs(a - b) for a, b in zip(res[0][1], res[1][1])) <= max(3, 0.05*sum(res[0][1]))
+    for f in range(2):
+        assert rel2(res[1][3][f], res[0][3][f]) < 1e-7
+    assert np.abs(res[1][3][2] - res[0][3][2]).max() < 1e-7
+
+
+def test_python_pc_classes_reproduce_native_pc_apply():
+    """Driving CPTRStage1PC + ILU through the PCBase-shaped Python classes == tp_pc_apply."""
+    from thermalporous_amd import preconditioners as pcs
+    from thermalporous_amd.engine import HipEngine
+    spec, u0, *_ = cases.c4_spe10_3d(Nx=7, Ny=9, Nz=6)
+    h = HipEngine(spec, dict(pc="cptr"))
+    u = cases.perturbed_state(spec, seed=9, amp=0.3)
+    h.set_old(u0)
+    h.set_dt(4000.0)
+    h.set_state(u)
+    h.jacobian()
+    pc = pcs.PC(h, {"decoup": "No", "vector": False}, prefix="sub_0_")
+    comp = pcs.CompositePC(pcs.CPTRStage1PC())
+    comp.setUp(pc)
+    x = np.random.default_rng(2).standard_normal((3,) + spec["phi"].shape)
+    h.vec_set("x", x)
+    comp.apply(pc, "x", "y_py")
+    h.pc_apply("x", "y_native")
+    assert rel2(h.vec_get("y_py"), h.vec_get("y_native")) < 1e-12
+    # ConvDiffSchurTwoPhasesPC.apply = one V-cycle on S~ (temperature field)
+    schur = pcs.ConvDiffSchurTwoPhasesPC()
+    schur.setUp(pc)
+    schur.apply(pc, "x", "ys")
+    h.amg_vcycle(1, "x", 1, "yv", 1)
+    assert rel2(h.vec_get("ys")[1], h.vec_get("yv")[1]) < 1e-14
+    h.close()
+
+
+def test_full_size_properties_c4():
+    """BASELINE config 4 at full size (60x220x85): size-independent properties of the GPU path --
+    pairwise cancellation of the face fluxes, linearity of every preconditioner stage, and the true
+    residual of the FGMRES solution."""
+    from thermalporous_amd.engine import HipEngine
+    spec, u0, *_ = cases.c4_spe10_3d(60, 220, 85)
+    nosrc = dict(spec)
+    nosrc["sources"] = None
+    h = HipEngine(nosrc, dict(pc="cptr", ksp_rtol=1e-8))
+    u = cases.perturbed_state(spec, seed=1, amp=0.05)
+    h.set_old(u)
+    h.set_state(u)
+    # u == u_old: the accumulation vanishes, the residual is the sum of face fluxes -> each field sums to 0
+    h.set_dt(50.0)
+    Rflux = h.residual()
+    for f in range(3):
+        assert abs(Rflux[f].sum()) <= 1e-9*np.abs(Rflux[f]).sum()
+    h.set_old(u0)
+    h.set_state(u)
+    h.jacobian()
+    h.pc_setup()
+    rng = np.random.default_rng(0)
+    x = rng.standard_normal(u.shape)
+    y = rng.standard_normal(u.shape)
+    for apply in (h.ilu_solve, h.stage1_apply, h.pc_apply):     # M(2x - 3y) = 2 Mx - 3 My
+        h.vec_set("x", x)
+        apply("x", "mx")
+        mx = h.vec_get("mx")
+        h.vec_set("x", y)
+        apply("x", "my")
+        my = h.vec_get("my")
+        h.vec_set("x", 2.0*x - 3.0*y)
+        apply("x", "mz")
+        assert rel2(h.vec_get("mz"), 2.0*mx - 3.0*my) < 1e-9
+    h.residual()
+    h.copy_residual_to("b")
+    its, reason, rn = h.fgmres("b", "d")
+    assert reason == 2 and its < 100
+    h.spmv("d", "Jd")
+    b = h.vec_get("b")
+    assert np.linalg.norm(h.vec_get("Jd") - b) <= 1.5e-8*np.linalg.norm(b)
+    h.close()

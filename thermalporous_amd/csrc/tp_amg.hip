@@ -135,6 +135,8 @@ struct LevelDev {
     const double *invd, *wm, *wp;
     double *b, *x, *x2, *e;
     int axis;
+    int pre, post;           // smoothing sweeps of this level: V(pre, post), post >= 1
+    int pad_;
 };
 
 __device__ __forceinline__ void nb_offsets(const GridDev &g, long (&off)[7]) {
@@ -196,6 +198,24 @@ __device__ __forceinline__ double resid_restrict_cell(const LevelDev &Lf, const 
     return v;
 }
 
+// (P^T r) at coarse cell tidc, r given as a vector
+__device__ __forceinline__ double restrict_cell(const LevelDev &Lf, const GridDev &gc, const double *__restrict__ r,
+                                                long tidc) {
+    int I[3];
+    cell_ijk(gc, tidc, I[0], I[1], I[2]);
+    const int a = Lf.axis;
+    int F[3] = {I[0], I[1], I[2]};
+    F[a] = 2 * I[a];
+    const GridDev &gf = Lf.g;
+    const int nfa = a == 0 ? gf.n0 : (a == 1 ? gf.n1 : gf.n2);
+    const long stride = a == 0 ? 1 : (a == 1 ? gf.n0 : gf.np);
+    const long f = gf.np + (long)F[0] + (long)gf.n0 * F[1] + gf.np * F[2];
+    double v = r[f];
+    if (F[a] - 1 >= 0) v += Lf.wp[f - stride] * r[f - stride];
+    if (F[a] + 1 < nfa) v += Lf.wm[f + stride] * r[f + stride];
+    return v;
+}
+
 // (P ec) at fine cell (F0,F1,F2)
 __device__ __forceinline__ double prolong_at(const LevelDev &Lf, const GridDev &gc, const double *__restrict__ ec,
                                              int F0, int F1, int F2) {
@@ -216,20 +236,22 @@ __device__ __forceinline__ double prolong_at(const LevelDev &Lf, const GridDev &
 // coarse-grid correction fused with the first post-smoothing sweep:
 //   x' = x + P ec ;  out = x' + invd (b - A x')
 __device__ __forceinline__ double prolong_jacobi_cell(const LevelDev &Lf, const GridDev &gc,
-                                                      const double *__restrict__ b, const double *__restrict__ x,
+                                                      const double *__restrict__ b, const double *x,
                                                       const double *__restrict__ ec, long tid) {
     const GridDev &g = Lf.g;
     int i0, i1, i2;
     cell_ijk(g, tid, i0, i1, i2);
     const long c = g.np + tid;
-    const double xc = x[c] + prolong_at(Lf, gc, ec, i0, i1, i2);
+    // x == nullptr: the level had no pre-smoothing (V(0,post)), its iterate is zero
+    auto xv = [&](long k) { return x ? x[k] : 0.0; };
+    const double xc = xv(c) + prolong_at(Lf, gc, ec, i0, i1, i2);
     double s = Lf.op.slot(0)[c] * xc;
-    if (i0 > 0)        s += Lf.op.slot(1)[c] * (x[c - 1] + prolong_at(Lf, gc, ec, i0 - 1, i1, i2));
-    if (i0 < g.n0 - 1) s += Lf.op.slot(2)[c] * (x[c + 1] + prolong_at(Lf, gc, ec, i0 + 1, i1, i2));
-    if (i1 > 0)        s += Lf.op.slot(3)[c] * (x[c - g.n0] + prolong_at(Lf, gc, ec, i0, i1 - 1, i2));
-    if (i1 < g.n1 - 1) s += Lf.op.slot(4)[c] * (x[c + g.n0] + prolong_at(Lf, gc, ec, i0, i1 + 1, i2));
-    if (i2 > 0)        s += Lf.op.slot(5)[c] * (x[c - g.np] + prolong_at(Lf, gc, ec, i0, i1, i2 - 1));
-    if (i2 < g.n2 - 1) s += Lf.op.slot(6)[c] * (x[c + g.np] + prolong_at(Lf, gc, ec, i0, i1, i2 + 1));
+    if (i0 > 0)        s += Lf.op.slot(1)[c] * (xv(c - 1) + prolong_at(Lf, gc, ec, i0 - 1, i1, i2));
+    if (i0 < g.n0 - 1) s += Lf.op.slot(2)[c] * (xv(c + 1) + prolong_at(Lf, gc, ec, i0 + 1, i1, i2));
+    if (i1 > 0)        s += Lf.op.slot(3)[c] * (xv(c - g.n0) + prolong_at(Lf, gc, ec, i0, i1 - 1, i2));
+    if (i1 < g.n1 - 1) s += Lf.op.slot(4)[c] * (xv(c + g.n0) + prolong_at(Lf, gc, ec, i0, i1 + 1, i2));
+    if (i2 > 0)        s += Lf.op.slot(5)[c] * (xv(c - g.np) + prolong_at(Lf, gc, ec, i0, i1, i2 - 1));
+    if (i2 < g.n2 - 1) s += Lf.op.slot(6)[c] * (xv(c + g.np) + prolong_at(Lf, gc, ec, i0, i1, i2 + 1));
     return xc + Lf.invd[c] * (b[c] - s);
 }
 
@@ -269,19 +291,7 @@ __global__ __launch_bounds__(256) void k_amg_restrict(LevelDev Lf, GridDev gc, c
                                                       double *__restrict__ rc) {
     const long tid = (long)blockIdx.x * blockDim.x + threadIdx.x;
     if (tid >= gc.nown) return;
-    int I[3];
-    cell_ijk(gc, tid, I[0], I[1], I[2]);
-    const int a = Lf.axis;
-    int F[3] = {I[0], I[1], I[2]};
-    F[a] = 2 * I[a];
-    const GridDev &gf = Lf.g;
-    const int nfa = a == 0 ? gf.n0 : (a == 1 ? gf.n1 : gf.n2);
-    const long stride = a == 0 ? 1 : (a == 1 ? gf.n0 : gf.np);
-    const long f = gf.np + (long)F[0] + (long)gf.n0 * F[1] + gf.np * F[2];
-    double v = r[f];
-    if (F[a] - 1 >= 0) v += Lf.wp[f - stride] * r[f - stride];
-    if (F[a] + 1 < nfa) v += Lf.wm[f + stride] * r[f + stride];
-    rc[gc.np + tid] = v;
+    rc[gc.np + tid] = restrict_cell(Lf, gc, r, tid);
 }
 __global__ __launch_bounds__(256) void k_amg_prolong_add(LevelDev Lf, GridDev gc, const double *__restrict__ ec,
                                                          double *x) {
@@ -306,20 +316,27 @@ __global__ __launch_bounds__(1024) void k_amg_tail(const LevelDev *lv, int l0, i
         __syncthreads();
     }
     lv = reinterpret_cast<const LevelDev *>(slv_raw);
+    (void)nu;
     // down-sweep
     for (int l = l0; l < nlev - 1; ++l) {
         const LevelDev L = lv[l];
         const GridDev gc = lv[l + 1].g;
         const double *b = (l == l0) ? b_top : L.b;
+        double *rc = lv[l + 1].b;
+        if (L.pre == 0) {                      // V(0,post): x = 0, the residual is b itself
+            for (long i = t; i < gc.nown; i += T) rc[gc.np + i] = restrict_cell(L, gc, b, i);
+            __syncthreads();
+            continue;
+        }
         double *cur = L.x, *oth = L.x2;
-        for (long i = t; i < L.g.nown; i += T) cur[L.g.np + i] = nu >= 2 ? pre2_cell(L, b, i) : L.invd[L.g.np + i] * b[L.g.np + i];
+        for (long i = t; i < L.g.nown; i += T)
+            cur[L.g.np + i] = L.pre >= 2 ? pre2_cell(L, b, i) : L.invd[L.g.np + i] * b[L.g.np + i];
         __syncthreads();
-        for (int k = 2; k < nu; ++k) {
+        for (int k = 2; k < L.pre; ++k) {
             for (long i = t; i < L.g.nown; i += T) oth[L.g.np + i] = jacobi_cell(L, b, cur, i);
             __syncthreads();
             double *tmp = cur; cur = oth; oth = tmp;
         }
-        double *rc = lv[l + 1].b;
         for (long i = t; i < gc.nown; i += T) rc[gc.np + i] = resid_restrict_cell(L, gc, b, cur, i);
         __syncthreads();
     }
@@ -342,15 +359,15 @@ __global__ __launch_bounds__(1024) void k_amg_tail(const LevelDev *lv, int l0, i
         const double *b = (l == l0) ? b_top : L.b;
         double *out = (l == l0) ? e_top : L.e;
         const double *ec = lv[l + 1].e;
-        // where the pre-smoothed iterate lives: x after an even number of extra sweeps, else x2
-        const int extra = nu >= 2 ? nu - 2 : 0;
-        double *src = (extra % 2 == 0) ? L.x : L.x2;
-        double *dst = (nu == 1) ? out : (src == L.x ? L.x2 : L.x);
+        // where the pre-smoothed iterate lives: x after an even number of extra sweeps, else x2; none if pre == 0
+        const int extra = L.pre >= 2 ? L.pre - 2 : 0;
+        const double *src = L.pre == 0 ? nullptr : ((extra % 2 == 0) ? L.x : L.x2);
+        double *dst = (L.post == 1) ? out : (src == L.x ? L.x2 : L.x);
         for (long i = t; i < L.g.nown; i += T) dst[L.g.np + i] = prolong_jacobi_cell(L, gc, b, src, ec, i);
         __syncthreads();
-        for (int k = 1; k < nu; ++k) {
+        for (int k = 1; k < L.post; ++k) {
             src = dst;
-            dst = (k == nu - 1) ? out : (src == L.x ? L.x2 : L.x);
+            dst = (k == L.post - 1) ? out : (src == L.x ? L.x2 : L.x);
             for (long i = t; i < L.g.nown; i += T) dst[L.g.np + i] = jacobi_cell(L, b, src, i);
             __syncthreads();
         }
@@ -375,8 +392,13 @@ static std::vector<int> schedule(const int n_[3], const double strength[3], int 
     return sched;
 }
 
-static LevelDev dev_of(const AmgLevel *L) {
+static LevelDev dev_of(const AmgLevel *L, int level, const tp_options &o) {
     LevelDev d;
+    const int nu = std::max(1, o.amg_nu);
+    const bool full = level < o.amg_full_levels;
+    d.pre = full ? nu : std::max(0, o.amg_coarse_pre);
+    d.post = full ? nu : std::max(1, o.amg_coarse_post);
+    d.pad_ = 0;
     d.g = L->g; d.op = L->op;
     d.invd = L->invd.p; d.wm = L->wm.p; d.wp = L->wp.p;
     d.b = L->b.p; d.x = L->x.p; d.x2 = L->x2.p; d.e = L->e.p;
@@ -439,7 +461,7 @@ void amg_setup(tp_ctx *c, Amg *amg, const Stencil &A0) {
     hipLaunchKernelGGL(k_amg_dense_inverse, dim3(1), dim3(256), 0, c->stream, Lc->g, Lc->op, n, amg->coarse_inv.p,
                        amg->coarse_inv.p + (size_t)n * n);
     std::vector<LevelDev> h;
-    for (auto *L : amg->lv) h.push_back(dev_of(L));
+    for (size_t l = 0; l < amg->lv.size(); ++l) h.push_back(dev_of(amg->lv[l], (int)l, c->opt));
     amg->lvhost.assign((const char *)h.data(), (const char *)h.data() + h.size() * sizeof(LevelDev));
     TP_HIP(hipMemcpyAsync(amg->lvdev.p, amg->lvhost.data(), amg->lvhost.size(), hipMemcpyHostToDevice, c->stream));
     TP_HIP(hipGetLastError());
@@ -448,24 +470,27 @@ void amg_setup(tp_ctx *c, Amg *amg, const Stencil &A0) {
 void amg_vcycle(tp_ctx *c, Amg *amg, const double *b, double *x) {
     TP_REQUIRE(amg && !amg->lv.empty(), "AMG not set up");
     TP_REQUIRE(x != amg->lv[0]->x.p && x != amg->lv[0]->x2.p && b != x, "aliasing in amg_vcycle");
-    const int nu = std::max(1, c->opt.amg_nu);
     const int nlev = (int)amg->lv.size(), lt = amg->tail_level;
     const dim3 bl(256);
-    std::vector<double *> xs(nlev, nullptr);       // pre-smoothed iterate of each big level
+    std::vector<double *> xs(nlev, nullptr);       // pre-smoothed iterate of each big level (null: none)
     // down-sweep over the big levels
     for (int l = 0; l < lt; ++l) {
         AmgLevel *L = amg->lv[l];
-        const LevelDev Ld = dev_of(L);
+        AmgLevel *Lc = amg->lv[l + 1];
+        const LevelDev Ld = dev_of(L, l, c->opt);
         const double *bl_ = (l == 0) ? b : L->b.p;
         const dim3 gr = grid_for(L->g.nown);
+        if (Ld.pre == 0) {                          // V(0,post): residual = b
+            hipLaunchKernelGGL(k_amg_restrict, grid_for(Lc->g.nown), bl, 0, c->stream, Ld, Lc->g, bl_, Lc->b.p);
+            continue;
+        }
         double *cur = L->x.p, *oth = L->x2.p;
-        hipLaunchKernelGGL(k_amg_pre, gr, bl, 0, c->stream, Ld, bl_, nu >= 2 ? 1 : 0, cur);
-        for (int k = 2; k < nu; ++k) {
+        hipLaunchKernelGGL(k_amg_pre, gr, bl, 0, c->stream, Ld, bl_, Ld.pre >= 2 ? 1 : 0, cur);
+        for (int k = 2; k < Ld.pre; ++k) {
             hipLaunchKernelGGL(k_amg_jacobi, gr, bl, 0, c->stream, Ld, bl_, cur, oth);
             std::swap(cur, oth);
         }
         xs[l] = cur;
-        AmgLevel *Lc = amg->lv[l + 1];
         if (L->g.nown >= amg->fuse_below) {
             hipLaunchKernelGGL(k_amg_resid, gr, bl, 0, c->stream, Ld, bl_, cur, oth);
             hipLaunchKernelGGL(k_amg_restrict, grid_for(Lc->g.nown), bl, 0, c->stream, Ld, Lc->g, oth, Lc->b.p);
@@ -479,28 +504,28 @@ void amg_vcycle(tp_ctx *c, Amg *amg, const double *b, double *x) {
         const double *bt = (lt == 0) ? b : Lt->b.p;
         double *et = (lt == 0) ? x : Lt->e.p;
         const int n = amg->ncoarse;
-        hipLaunchKernelGGL(k_amg_tail, dim3(1), dim3(1024), 0, c->stream, (const LevelDev *)amg->lvdev.p, lt, nlev, nu, n,
-                           amg->coarse_inv.p + (size_t)n * n, bt, et);
+        hipLaunchKernelGGL(k_amg_tail, dim3(1), dim3(1024), 0, c->stream, (const LevelDev *)amg->lvdev.p, lt, nlev,
+                           c->opt.amg_nu, n, amg->coarse_inv.p + (size_t)n * n, bt, et);
     }
     // up-sweep over the big levels
     for (int l = lt - 1; l >= 0; --l) {
         AmgLevel *L = amg->lv[l];
         AmgLevel *Lc = amg->lv[l + 1];
-        const LevelDev Ld = dev_of(L);
+        const LevelDev Ld = dev_of(L, l, c->opt);
         const double *bl_ = (l == 0) ? b : L->b.p;
         double *out = (l == 0) ? x : L->e.p;
         const dim3 gr = grid_for(L->g.nown);
         double *src = xs[l];
-        double *dst = (nu == 1) ? out : (src == L->x.p ? L->x2.p : L->x.p);
-        if (L->g.nown >= amg->fuse_below) {
+        double *dst = (Ld.post == 1) ? out : (src == L->x.p ? L->x2.p : L->x.p);
+        if (src && L->g.nown >= amg->fuse_below) {
             hipLaunchKernelGGL(k_amg_prolong_add, gr, bl, 0, c->stream, Ld, Lc->g, Lc->e.p, src);
             hipLaunchKernelGGL(k_amg_jacobi, gr, bl, 0, c->stream, Ld, bl_, src, dst);
         } else {
-            hipLaunchKernelGGL(k_amg_prolong_jacobi, gr, bl, 0, c->stream, Ld, Lc->g, bl_, src, Lc->e.p, dst);
+            hipLaunchKernelGGL(k_amg_prolong_jacobi, gr, bl, 0, c->stream, Ld, Lc->g, bl_, (const double *)src, Lc->e.p, dst);
         }
-        for (int k = 1; k < nu; ++k) {
+        for (int k = 1; k < Ld.post; ++k) {
             src = dst;
-            dst = (k == nu - 1) ? out : (src == L->x.p ? L->x2.p : L->x.p);
+            dst = (k == Ld.post - 1) ? out : (src == L->x.p ? L->x2.p : L->x.p);
             hipLaunchKernelGGL(k_amg_jacobi, gr, bl, 0, c->stream, Ld, bl_, src, dst);
         }
     }

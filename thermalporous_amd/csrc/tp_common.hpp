@@ -182,6 +182,8 @@ void multi_dot(tp_ctx *c, int nf, const double *V, long vstride, int k, const do
 void multi_axpy(tp_ctx *c, int nf, const double *V, long vstride, int k, const double *hcoef_host, double sign,
                 double *w);          // w += sign * sum_i h_i V_i
 double norm2(tp_ctx *c, int nf, const double *x);
+// h = V^T w ; w -= V h ; host_out[0..k-1] = h, host_out[k] = ||w||^2  (one host sync)
+void orthogonalize(tp_ctx *c, int nf, const double *V, long vstride, int k, double *w, double *host_out);
 void field_minmax(tp_ctx *c, const double *x, double *lo, double *hi);
 void field_clamp01(tp_ctx *c, double *x);
 // stencil operators

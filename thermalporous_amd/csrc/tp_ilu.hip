@@ -21,6 +21,7 @@
 // application.  The chunk of step s+1 is prefetched into registers while step s computes.
 // HBM-bound: (3+4) b^2 doubles per cell plus vectors, the traffic of one block SpMV.
 #include "tp_common.hpp"
+#include <cstdlib>
 
 namespace tp {
 
@@ -233,8 +234,11 @@ __device__ __forceinline__ double chunk_get(const double2 (&v)[NP], int e) {
     return (e & 1) ? v[e >> 1].y : v[e >> 1].x;
 }
 
-// x = addto + M^-1 r  (forward then backward sweep of one tile by one wavefront)
-template <int B>
+// x = addto + M^-1 r  (forward then backward sweep of one tile by one wavefront).
+// Three register buffers form a prefetch ring: while step s computes from one buffer the chunks of
+// steps s+1 and s+2 are in flight into the other two, and the buffer just consumed is refilled with
+// step s+3 -- a single wave per CU keeps ~40 KB of HBM reads outstanding.
+template <int B, bool DEPTH2>
 __global__ __launch_bounds__(64) void k_ilu_solve(IluGeom G, const double *__restrict__ fwd,
                                                   const double *__restrict__ bwd, const double *__restrict__ rhs,
                                                   double *__restrict__ ytmp, double *x, const double *addto) {
@@ -243,39 +247,32 @@ __global__ __launch_bounds__(64) void k_ilu_solve(IluGeom G, const double *__res
     const long nt = G.g.ntot;
     const TileInfo ti = tile_info(G, tile, lane);
     const long chunk0 = (long)tile * G.nsteps;
-    double yp[B];
-#pragma unroll
-    for (int r = 0; r < B; ++r) yp[r] = 0.0;
+    const int ns = G.nsteps;
+    constexpr int RING = DEPTH2 ? 3 : 2;
+    int l0;
+    long c;
     // ---- forward: y_c = r_c - sum_lower B_cm y_m -------------------------------------------------
     {
-        double2 nxt[L::PF];
-        double rn[B];
-        int l0;
-        long c;
-        bool okn = tile_cell(G, ti, 0, l0, c);
-        load_chunk<L::PF>(fwd + chunk0 * (L::PF * 128), lane, nxt);
+        double yp[B];
 #pragma unroll
-        for (int r = 0; r < B; ++r) rn[r] = okn ? rhs[(long)r * nt + c] : 0.0;
-        for (int s = 0; s < G.nsteps; ++s) {
-            double2 cur[L::PF];
-            double y[B];
-            const bool ok = okn;
+        for (int r = 0; r < B; ++r) yp[r] = 0.0;
+        double2 buf[RING][L::PF];
+        double rr[RING][B];
+        bool okk[RING];
+        auto load = [&](int k, int step) {
+            okk[k] = tile_cell(G, ti, step, l0, c);
+            load_chunk<L::PF>(fwd + (chunk0 + step) * (L::PF * 128), lane, buf[k]);
 #pragma unroll
-            for (int i = 0; i < L::PF; ++i) cur[i] = nxt[i];
-#pragma unroll
-            for (int r = 0; r < B; ++r) y[r] = rn[r];
-            if (s + 1 < G.nsteps) {                    // prefetch the next step while this one computes
-                okn = tile_cell(G, ti, s + 1, l0, c);
-                load_chunk<L::PF>(fwd + (chunk0 + s + 1) * (L::PF * 128), lane, nxt);
-#pragma unroll
-                for (int r = 0; r < B; ++r) rn[r] = okn ? rhs[(long)r * nt + c] : 0.0;
-            }
-            double yn[3][B];
+            for (int r = 0; r < B; ++r) rr[k][r] = okk[k] ? rhs[(long)r * nt + c] : 0.0;
+        };
+        auto step = [&](int k, int s) {
+            double yn[3][B], y[B];
 #pragma unroll
             for (int r = 0; r < B; ++r) {
                 yn[0][r] = yp[r];
                 yn[1][r] = __shfl_up(yp[r], 1, 64);
                 yn[2][r] = __shfl_up(yp[r], G.t1, 64);
+                y[r] = rr[k][r];
             }
             // B_cm is stored as zero where the neighbour is outside the tile, so no branches here
 #pragma unroll
@@ -283,13 +280,25 @@ __global__ __launch_bounds__(64) void k_ilu_solve(IluGeom G, const double *__res
 #pragma unroll
                 for (int r = 0; r < B; ++r)
 #pragma unroll
-                    for (int q = 0; q < B; ++q) y[r] -= chunk_get<L::PF>(cur, (a * B + r) * B + q) * yn[a][q];
+                    for (int q = 0; q < B; ++q) y[r] -= chunk_get<L::PF>(buf[k], (a * B + r) * B + q) * yn[a][q];
             double *ych = ytmp + (chunk0 + s) * (L::PY * 128);
 #pragma unroll
             for (int r = 0; r < B; ++r) {
-                y[r] = ok ? y[r] : 0.0;
+                y[r] = okk[k] ? y[r] : 0.0;
                 ych[(r >> 1) * 128 + lane * 2 + (r & 1)] = y[r];
                 yp[r] = y[r];
+            }
+        };
+#pragma unroll
+        for (int k = 0; k < RING; ++k)
+            if (k < ns) load(k, k);
+        for (int s = 0; s < ns; s += RING) {
+#pragma unroll
+            for (int k = 0; k < RING; ++k) {
+                if (s + k < ns) {
+                    step(k, s + k);
+                    if (s + k + RING < ns) load(k, s + k + RING);
+                }
             }
         }
     }
@@ -298,48 +307,32 @@ __global__ __launch_bounds__(64) void k_ilu_solve(IluGeom G, const double *__res
         double xp[B];
 #pragma unroll
         for (int r = 0; r < B; ++r) xp[r] = 0.0;
-        double2 nxt[L::PB], ynxt[L::PY];
-        double an[B];
-        int l0;
-        long c;
-        bool okn = tile_cell(G, ti, G.nsteps - 1, l0, c);
-        long cn = c;
-        load_chunk<L::PB>(bwd + (chunk0 + G.nsteps - 1) * (L::PB * 128), lane, nxt);
-        load_chunk<L::PY>(ytmp + (chunk0 + G.nsteps - 1) * (L::PY * 128), lane, ynxt);
+        double2 buf[RING][L::PB], ybuf[RING][L::PY];
+        double aa[RING][B];
+        bool okk[RING];
+        long cc[RING];
+        auto load = [&](int k, int step) {
+            okk[k] = tile_cell(G, ti, step, l0, c);
+            cc[k] = c;
+            load_chunk<L::PB>(bwd + (chunk0 + step) * (L::PB * 128), lane, buf[k]);
+            load_chunk<L::PY>(ytmp + (chunk0 + step) * (L::PY * 128), lane, ybuf[k]);
 #pragma unroll
-        for (int r = 0; r < B; ++r) an[r] = (okn && addto) ? addto[(long)r * nt + c] : 0.0;
-        for (int s = G.nsteps - 1; s >= 0; --s) {
-            double2 cur[L::PB], ycur[L::PY];
-            double av[B];
-            const bool ok = okn;
-            const long cc = cn;
-#pragma unroll
-            for (int i = 0; i < L::PB; ++i) cur[i] = nxt[i];
-#pragma unroll
-            for (int i = 0; i < L::PY; ++i) ycur[i] = ynxt[i];
-#pragma unroll
-            for (int r = 0; r < B; ++r) av[r] = an[r];
-            if (s > 0) {
-                okn = tile_cell(G, ti, s - 1, l0, c);
-                cn = c;
-                load_chunk<L::PB>(bwd + (chunk0 + s - 1) * (L::PB * 128), lane, nxt);
-                load_chunk<L::PY>(ytmp + (chunk0 + s - 1) * (L::PY * 128), lane, ynxt);
-#pragma unroll
-                for (int r = 0; r < B; ++r) an[r] = (okn && addto) ? addto[(long)r * nt + c] : 0.0;
-            }
-            double xn[3][B];
+            for (int r = 0; r < B; ++r) aa[k][r] = (okk[k] && addto) ? addto[(long)r * nt + c] : 0.0;
+        };
+        auto step = [&](int k) {
+            double xn[3][B], xv[B];
 #pragma unroll
             for (int r = 0; r < B; ++r) {
                 xn[0][r] = xp[r];
                 xn[1][r] = __shfl_down(xp[r], 1, 64);
                 xn[2][r] = __shfl_down(xp[r], G.t1, 64);
             }
-            double xv[B];
 #pragma unroll
             for (int r = 0; r < B; ++r) {
                 double v = 0.0;
 #pragma unroll
-                for (int q = 0; q < B; ++q) v += chunk_get<L::PB>(cur, (3 * B + r) * B + q) * chunk_get<L::PY>(ycur, q);
+                for (int q = 0; q < B; ++q)
+                    v += chunk_get<L::PB>(buf[k], (3 * B + r) * B + q) * chunk_get<L::PY>(ybuf[k], q);
                 xv[r] = v;
             }
 #pragma unroll
@@ -347,12 +340,26 @@ __global__ __launch_bounds__(64) void k_ilu_solve(IluGeom G, const double *__res
 #pragma unroll
                 for (int r = 0; r < B; ++r)
 #pragma unroll
-                    for (int q = 0; q < B; ++q) xv[r] -= chunk_get<L::PB>(cur, (a * B + r) * B + q) * xn[a][q];
+                    for (int q = 0; q < B; ++q) xv[r] -= chunk_get<L::PB>(buf[k], (a * B + r) * B + q) * xn[a][q];
 #pragma unroll
             for (int r = 0; r < B; ++r) {
-                xv[r] = ok ? xv[r] : 0.0;
+                xv[r] = okk[k] ? xv[r] : 0.0;
                 xp[r] = xv[r];
-                if (ok) x[(long)r * nt + cc] = av[r] + xv[r];
+                if (okk[k]) x[(long)r * nt + cc[k]] = aa[k][r] + xv[r];
+            }
+        };
+        // the forward sweep's y of the last steps may still be in flight as stores: same-lane same-address
+        // loads are ordered after them by the memory pipeline
+#pragma unroll
+        for (int k = 0; k < RING; ++k)
+            if (ns - 1 - k >= 0) load(k, ns - 1 - k);
+        for (int s = ns - 1; s >= 0; s -= RING) {
+#pragma unroll
+            for (int k = 0; k < RING; ++k) {
+                if (s - k >= 0) {
+                    step(k);
+                    if (s - k - RING >= 0) load(k, s - k - RING);
+                }
             }
         }
     }
@@ -414,12 +421,13 @@ void ilu_factor(tp_ctx *c) {
 void ilu_solve(tp_ctx *c, const double *r, double *x, const double *addto) {
     TP_REQUIRE(c->ilu.slots > 0, "ILU not factored");
     const IluGeom G = geom_of(c);
-    if (c->b == 3)
-        hipLaunchKernelGGL(k_ilu_solve<3>, dim3(c->ilu.ntiles), dim3(64), 0, c->stream, G, c->ilu.fwd.p,
-                           c->ilu.bwd.p, r, c->ilu.ytmp.p, x, addto);
-    else
-        hipLaunchKernelGGL(k_ilu_solve<2>, dim3(c->ilu.ntiles), dim3(64), 0, c->stream, G, c->ilu.fwd.p,
-                           c->ilu.bwd.p, r, c->ilu.ytmp.p, x, addto);
+    static const bool deep = !(getenv("TP_ILU_DEPTH") && atoi(getenv("TP_ILU_DEPTH")) == 1);
+#define TP_ILU_LAUNCH(BB, DD)                                                                                  \
+    hipLaunchKernelGGL((k_ilu_solve<BB, DD>), dim3(c->ilu.ntiles), dim3(64), 0, c->stream, G, c->ilu.fwd.p, \
+                       c->ilu.bwd.p, r, c->ilu.ytmp.p, x, addto)
+    if (c->b == 3) { if (deep) TP_ILU_LAUNCH(3, true); else TP_ILU_LAUNCH(3, false); }
+    else           { if (deep) TP_ILU_LAUNCH(2, true); else TP_ILU_LAUNCH(2, false); }
+#undef TP_ILU_LAUNCH
     TP_HIP(hipGetLastError());
 }
 

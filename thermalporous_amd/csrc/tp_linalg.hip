@@ -152,6 +152,50 @@ void multi_axpy(tp_ctx *c, int nf, const double *V, long vstride, int k, const d
     TP_HIP(hipStreamSynchronize(c->stream));
 }
 
+// ---- one Gram-Schmidt step with a single host sync -------------------------------------------------
+// h = V^T w (k dots) ; w -= V h ; ||w||^2 -- the coefficients never leave the device between the dot and
+// the update, so an FGMRES iteration pays one D2H copy + sync here instead of three.
+__global__ __launch_bounds__(256) void k_multi_axpy_norm(GridDev g, int nf, const double *V, long vstride, int k,
+                                                         const double *h, double *w, double *partial, long nwaves) {
+    const long wave = ((long)blockIdx.x * blockDim.x + threadIdx.x) >> 6;
+    const int lane = threadIdx.x & 63;
+    if (wave >= nwaves) return;
+    const long nall = g.nown * nf;
+    double acc = 0.0;
+#pragma unroll
+    for (int j = 0; j < MD_CHUNK; ++j) {
+        const long t = (wave * MD_CHUNK + j) * 64 + lane;
+        if (t < nall) {
+            const long f = t / g.nown, i = t - f * g.nown;
+            const long idx = f * g.ntot + g.np + i;
+            double s = 0.0;
+            for (int q = 0; q < k; ++q) s += h[q] * V[(long)q * vstride + idx];
+            const double wn = w[idx] - s;
+            w[idx] = wn;
+            acc += wn * wn;
+        }
+    }
+    acc = wave_sum(acc);
+    if (lane == 0) partial[wave] = acc;
+}
+
+void orthogonalize(tp_ctx *c, int nf, const double *V, long vstride, int k, double *w, double *host_out) {
+    const long nw = md_nwaves(c, nf);
+    if ((long)c->gs_partial.n < (long)(k + 1) * nw) c->gs_partial.alloc((size_t)(k + 33) * nw);
+    if ((long)c->red_out.n < k + 1) c->red_out.alloc(k + 65);
+    hipLaunchKernelGGL(k_multi_dot, grid_for(nw * 64), dim3(256), 0, c->stream, c->g, nf, V, vstride, k, w,
+                       (const double *)nullptr, c->gs_partial.p, nw);
+    hipLaunchKernelGGL(k_reduce_partials, dim3(k), dim3(256), 0, c->stream, c->gs_partial.p, nw, c->red_out.p);
+    allreduce_sum(c, c->red_out.p, k);
+    hipLaunchKernelGGL(k_multi_axpy_norm, grid_for(nw * 64), dim3(256), 0, c->stream, c->g, nf, V, vstride, k,
+                       c->red_out.p, w, c->gs_partial.p, nw);
+    hipLaunchKernelGGL(k_reduce_partials, dim3(1), dim3(256), 0, c->stream, c->gs_partial.p, nw, c->red_out.p + k);
+    TP_HIP(hipGetLastError());
+    allreduce_sum(c, c->red_out.p + k, 1);
+    TP_HIP(hipMemcpyAsync(host_out, c->red_out.p, sizeof(double) * (k + 1), hipMemcpyDeviceToHost, c->stream));
+    TP_HIP(hipStreamSynchronize(c->stream));
+}
+
 // ---- saturation guard (thermalmodel.py:193-229): min/max and clamp of one field over owned cells -----
 __global__ __launch_bounds__(256) void k_minmax(GridDev g, const double *x, double *partial) {
     __shared__ double smin[4], smax[4];

@@ -109,6 +109,7 @@ void pc_setup(tp_ctx *c) {
                              (uintptr_t)c->Sm.p, (uintptr_t)c->ilu.fwd.p, (uintptr_t)c->amg_p, (uintptr_t)c->amg_T,
                              (uintptr_t)c->w1.p, (uintptr_t)c->w3.p, (uintptr_t)c->w4.p, (uintptr_t)c->dcoef.p,
                              (uintptr_t)c->opt.amg_nu, (uintptr_t)c->opt.pc_kind, (uintptr_t)c->opt.decoup,
+                             (uintptr_t)c->opt.amg_full_levels, (uintptr_t)c->opt.amg_coarse_pre, (uintptr_t)c->opt.amg_coarse_post,
                              (uintptr_t)c->ilu.ntiles, (uintptr_t)c->ilu.nsteps};
     uintptr_t h = 1469598103934665603ull;
     for (uintptr_t v : sig) h = (h ^ v) * 1099511628211ull;
@@ -260,9 +261,8 @@ int fgmres(tp_ctx *c, const double *bvec, double *x, int *its_out, double *rnorm
             pc_apply(c, vj, zj);                                            // z_j = M^-1 v_j
             if (c->comm) halo_exchange(c, g, zj, B, g.ntot);
             spmv_block(c, c->J.p, zj, w);                                   // w = J z_j
-            multi_dot(c, B, c->V.p, nv, j + 1, w, nullptr, hcol.data());    // h = V^T w   (VecMDot)
-            multi_axpy(c, B, c->V.p, nv, j + 1, hcol.data(), -1.0, w);      // w -= V h    (VecMAXPY)
-            const double hn = norm2(c, B, w);
+            orthogonalize(c, B, c->V.p, nv, j + 1, w, hcol.data());         // h = V^T w ; w -= V h ; ||w||^2
+            const double hn = std::sqrt(hcol[j + 1]);
             for (int i = 0; i <= j; ++i) H[(size_t)i * m + j] = hcol[i];
             H[(size_t)(j + 1) * m + j] = hn;
             for (int i = 0; i < j; ++i) {                                   // previous Givens rotations
