@@ -99,6 +99,11 @@ int tp_set_options(tp_ctx *ctx, const tp_options *opt);
  * (torch.distributed), then every rank calls tp_comm_init (RCCL ncclCommInitRank). */
 int tp_comm_unique_id(void *id128);
 int tp_comm_init(tp_ctx *ctx, const void *id128);
+/* in-process slab group: N contexts driven by N host threads on ONE GPU exchange through device copies
+ * instead of RCCL (same call sequence) -- validates the slab algorithm where only one GPU exists. */
+int tp_local_group_create(int32_t nranks, void **group);
+int tp_local_group_destroy(void *group);
+int tp_comm_init_local(tp_ctx *ctx, void *group);
 
 /* problem data: geo fields (homogeneousgeo.py:13-20, SPE10model*.py) -- arrays of ntot doubles
  * (slab + halo planes); name in {"phi","K0","K1","K2","kT"}.  tp_finalize_fields builds the face

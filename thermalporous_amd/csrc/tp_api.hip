@@ -5,6 +5,8 @@
 #include <cmath>
 #include <algorithm>
 #include <map>
+#include <mutex>
+#include <condition_variable>
 
 namespace tp {
 
@@ -18,13 +20,62 @@ void set_error(const std::string &msg) { g_err = msg; }
             throw tp::Error(std::string(#call) + " failed: " + ncclGetErrorString(r_));        \
     } while (0)
 
+// ---- in-process slab group: N contexts (threads) on one GPU exchange through device-to-device copies ------
+// Same call sequence and same buffer arithmetic as the RCCL path below; exists so that the slab
+// algorithm can be validated end to end on a single GPU (tests/test_gpu_slabs.py).
+struct LocalGroup {
+    int n = 0;
+    std::mutex mu;
+    std::condition_variable cv;
+    int arrived = 0;
+    long generation = 0;
+    std::vector<const void *> ptr;       // published buffer of every rank
+    std::vector<std::vector<double>> red;
+    void barrier() {
+        std::unique_lock<std::mutex> lk(mu);
+        const long gen = generation;
+        if (++arrived == n) { arrived = 0; ++generation; cv.notify_all(); }
+        else cv.wait(lk, [&] { return generation != gen; });
+    }
+};
+
+static void lg_publish(tp_ctx *c, const void *p) {
+    TP_HIP(hipStreamSynchronize(c->stream));          // my data is complete before anybody reads it
+    c->lgroup->ptr[c->grid.rank] = p;
+    c->lgroup->barrier();
+}
+static void lg_done(tp_ctx *c) {
+    TP_HIP(hipStreamSynchronize(c->stream));          // my copies are complete before sources may change
+    c->lgroup->barrier();
+}
+
 // One 1-cell halo plane per side along axis 2; each plane of each field is contiguous, so the
 // exchange is 2*nf send/recv pairs in one RCCL group on the compute stream (<= 2 neighbours, one
 // xGMI link each).
 void halo_exchange(tp_ctx *c, const GridDev &g, double *x, int nf, long fstride) {
-    if (!c->comm) return;
-    ncclComm_t comm = (ncclComm_t)c->comm;
+    if (!c->dist) return;
     const int lo = c->grid.rank - 1, hi = c->grid.rank + 1;
+    if (c->lgroup) {
+        lg_publish(c, x);
+        for (int f = 0; f < nf; ++f) {
+            double *p = x + (long)f * fstride;
+            if (g.nb_lo) {       // neighbour's last owned plane -> my lower halo
+                int nlo, nhi;
+                slab_of(c, lo, nlo, nhi);
+                const double *q = (const double *)c->lgroup->ptr[lo] + (long)f * (g.np * (nhi - nlo + 2));
+                TP_HIP(hipMemcpyAsync(p, q + g.np * (nhi - nlo), sizeof(double) * g.np, hipMemcpyDeviceToDevice, c->stream));
+            }
+            if (g.nb_hi) {       // neighbour's first owned plane -> my upper halo
+                int nlo, nhi;
+                slab_of(c, hi, nlo, nhi);
+                const double *q = (const double *)c->lgroup->ptr[hi] + (long)f * (g.np * (nhi - nlo + 2));
+                TP_HIP(hipMemcpyAsync(p + g.np * (g.n2 + 1), q + g.np, sizeof(double) * g.np, hipMemcpyDeviceToDevice, c->stream));
+            }
+        }
+        lg_done(c);
+        return;
+    }
+    ncclComm_t comm = (ncclComm_t)c->comm;
     TP_NCCL(ncclGroupStart());
     for (int f = 0; f < nf; ++f) {
         double *p = x + (long)f * fstride;
@@ -49,22 +100,56 @@ void slab_of(const tp_ctx *c, int rank, int &lo, int &hi) {
 // Every rank broadcasts the owned part of each of its planes into the same place of everybody's global
 // array (uneven slabs: one ncclBroadcast per (plane, root) inside one group).
 void gather_slabs(tp_ctx *c, const double *local, long lstride, double *global, long gstride, int nplanes) {
-    TP_REQUIRE(c->comm, "gather_slabs without a communicator");
-    ncclComm_t comm = (ncclComm_t)c->comm;
+    TP_REQUIRE(c->dist, "gather_slabs without a communicator");
     const long np = c->g.np;
+    if (c->lgroup) {
+        // NOTE: lstride is the same on every rank only when it is expressed in this rank's ntot; ranks
+        // publish (pointer, stride) pairs
+        struct Pub { const double *p; long stride; };
+        Pub mine{local, lstride};
+        lg_publish(c, &mine);
+        for (int r = 0; r < c->grid.nranks; ++r) {
+            int lo, hi;
+            slab_of(c, r, lo, hi);
+            const Pub *pr = (const Pub *)c->lgroup->ptr[r];
+            for (int p = 0; p < nplanes; ++p)
+                TP_HIP(hipMemcpyAsync(global + (long)p * gstride + np * (lo + 1), pr->p + (long)p * pr->stride + np,
+                                      sizeof(double) * np * (hi - lo), hipMemcpyDeviceToDevice, c->stream));
+        }
+        lg_done(c);
+        return;
+    }
+    ncclComm_t comm = (ncclComm_t)c->comm;
     TP_NCCL(ncclGroupStart());
     for (int p = 0; p < nplanes; ++p)
         for (int r = 0; r < c->grid.nranks; ++r) {
             int lo, hi;
             slab_of(c, r, lo, hi);
-            TP_NCCL(ncclBroadcast(local + (long)p * lstride + np, global + (long)p * gstride + np * (lo + 1),
-                                  (size_t)np * (hi - lo), ncclDouble, r, comm, c->stream));
+            double *dst = global + (long)p * gstride + np * (lo + 1);
+            // sendbuff is only read on the root; elsewhere pass the (valid, large enough) receive buffer
+            const double *src = (r == c->grid.rank) ? local + (long)p * lstride + np : dst;
+            TP_NCCL(ncclBroadcast(src, dst, (size_t)np * (hi - lo), ncclDouble, r, comm, c->stream));
         }
     TP_NCCL(ncclGroupEnd());
 }
 
 void allreduce_sum(tp_ctx *c, double *dev, int n) {
-    if (!c->comm || n <= 0) return;
+    if (!c->dist || n <= 0) return;
+    if (c->lgroup) {
+        LocalGroup *G = c->lgroup;
+        std::vector<double> &mine = G->red[c->grid.rank];
+        mine.resize(n);
+        TP_HIP(hipMemcpyAsync(mine.data(), dev, sizeof(double) * n, hipMemcpyDeviceToHost, c->stream));
+        TP_HIP(hipStreamSynchronize(c->stream));
+        G->barrier();
+        std::vector<double> sum(n, 0.0);
+        for (int r = 0; r < G->n; ++r)                 // fixed order: identical result on every rank
+            for (int i = 0; i < n; ++i) sum[i] += G->red[r][i];
+        G->barrier();                                  // everybody has read before anybody overwrites
+        TP_HIP(hipMemcpyAsync(dev, sum.data(), sizeof(double) * n, hipMemcpyHostToDevice, c->stream));
+        TP_HIP(hipStreamSynchronize(c->stream));
+        return;
+    }
     TP_NCCL(ncclAllReduce(dev, dev, n, ncclDouble, ncclSum, (ncclComm_t)c->comm, c->stream));
 }
 
@@ -198,9 +283,40 @@ int tp_comm_init(tp_ctx *c, const void *id128) {
     ncclComm_t comm;
     TP_NCCL(ncclCommInitRank(&comm, c->grid.nranks, id, c->grid.rank));
     c->comm = (ncclComm *)comm;
+    c->dist = true;
     int lo, hi;
     slab_of(c, c->grid.rank, lo, hi);
     TP_REQUIRE(lo == c->grid.off2 && hi - lo == c->grid.n2, "slab of this rank does not follow the library's partition rule");
+    TP_API_END
+}
+
+int tp_local_group_create(int32_t nranks, void **group) {
+    TP_API_BEGIN
+    TP_REQUIRE(nranks >= 2 && group, "bad arguments");
+    LocalGroup *G = new LocalGroup();
+    G->n = nranks;
+    G->ptr.assign(nranks, nullptr);
+    G->red.resize(nranks);
+    *group = G;
+    TP_API_END
+}
+
+int tp_local_group_destroy(void *group) {
+    TP_API_BEGIN
+    delete (LocalGroup *)group;
+    TP_API_END
+}
+
+int tp_comm_init_local(tp_ctx *c, void *group) {
+    TP_API_BEGIN
+    TP_REQUIRE(c && group, "null argument");
+    LocalGroup *G = (LocalGroup *)group;
+    TP_REQUIRE(c->grid.nranks == G->n, "group size differs from the context's nranks");
+    int lo, hi;
+    slab_of(c, c->grid.rank, lo, hi);
+    TP_REQUIRE(lo == c->grid.off2 && hi - lo == c->grid.n2, "slab of this rank does not follow the library's partition rule");
+    c->lgroup = G;
+    c->dist = true;
     TP_API_END
 }
 
@@ -320,7 +436,7 @@ int tp_clamp_saturation(tp_ctx *c) {
 
 int tp_residual(tp_ctx *c, double *norm2_out) {
     TP_API_BEGIN
-    if (c->comm) halo_exchange(c, c->g, c->u.p, c->b, c->g.ntot);
+    if (c->dist) halo_exchange(c, c->g, c->u.p, c->b, c->g.ntot);
     assemble(c, false, false);
     const double n = norm2(c, c->b, c->R.p);
     if (norm2_out) *norm2_out = n;
@@ -329,7 +445,7 @@ int tp_residual(tp_ctx *c, double *norm2_out) {
 
 int tp_jacobian(tp_ctx *c) {
     TP_API_BEGIN
-    if (c->comm) halo_exchange(c, c->g, c->u.p, c->b, c->g.ntot);
+    if (c->dist) halo_exchange(c, c->g, c->u.p, c->b, c->g.ntot);
     assemble(c, true, c->opt.pc_kind == 1);
     c->pc_ready = false;
     TP_HIP(hipStreamSynchronize(c->stream));
@@ -405,7 +521,7 @@ int tp_spmv(tp_ctx *c, int32_t x, int32_t y) {
     TP_API_BEGIN
     TP_REQUIRE(c->jac_ready, "Jacobian not assembled");
     TP_REQUIRE(x != y, "tp_spmv: x and y must differ");
-    if (c->comm) halo_exchange(c, c->g, vec_of(c, x).p, c->b, c->g.ntot);
+    if (c->dist) halo_exchange(c, c->g, vec_of(c, x).p, c->b, c->g.ntot);
     spmv_block(c, c->J.p, vec_of(c, x).p, vec_of(c, y).p);
     TP_API_END
 }
@@ -464,7 +580,7 @@ int tp_amg_vcycle(tp_ctx *c, int32_t which, int32_t field_b, int32_t b, int32_t 
     TP_REQUIRE(c->pc_ready, "AMG not set up");
     Amg *amg = which == 0 ? c->amg_p : c->amg_T;
     TP_REQUIRE(amg, "this AMG hierarchy does not exist for the selected preconditioner");
-    TP_REQUIRE(!c->comm, "tp_amg_vcycle works on slab vectors: single-slab contexts only");
+    TP_REQUIRE(!c->dist, "tp_amg_vcycle works on slab vectors: single-slab contexts only");
     TP_REQUIRE(field_b >= 0 && field_b < c->b && field_x >= 0 && field_x < c->b, "bad field index");
     TP_REQUIRE(!(b == x && field_b == field_x), "b and x must differ");
     amg_vcycle(c, amg, vec_of(c, b).p + (long)field_b * c->g.ntot, vec_of(c, x).p + (long)field_x * c->g.ntot);
@@ -474,7 +590,7 @@ int tp_amg_vcycle(tp_ctx *c, int32_t which, int32_t field_b, int32_t b, int32_t 
 int tp_schur_apply(tp_ctx *c, int32_t x, int32_t y) {
     TP_API_BEGIN
     TP_REQUIRE(c->pc_ready && c->amg_T, "S~ AMG not set up (pc_cptr only)");
-    TP_REQUIRE(!c->comm, "tp_schur_apply works on slab vectors: single-slab contexts only");
+    TP_REQUIRE(!c->dist, "tp_schur_apply works on slab vectors: single-slab contexts only");
     TP_REQUIRE(x != y, "x and y must differ");
     amg_vcycle(c, c->amg_T, vec_of(c, x).p + c->g.ntot, vec_of(c, y).p + c->g.ntot);
     TP_API_END
@@ -513,7 +629,10 @@ int tp_time_kernel(tp_ctx *c, int32_t which, int32_t reps, double *ms_avg) {
         switch (which) {
             case 0: spmv_block(c, c->J.p, c->R.p, c->w2.p); break;
             case 1: ilu_solve(c, c->R.p, c->w2.p, nullptr); break;
-            case 2: amg_vcycle(c, c->amg_p, c->R.p, c->w2.p); break;
+            case 2:
+                if (c->dist) amg_vcycle(c, c->amg_p, c->gvec.p, c->gvec.p + 2 * c->gfull.ntot);   // global-grid buffers
+                else amg_vcycle(c, c->amg_p, c->R.p, c->w2.p);
+                break;
             case 3: assemble(c, true, c->opt.pc_kind == 1); break;
             case 4: pc_apply(c, c->R.p, c->dx.p); break;
             default: throw Error("unknown kernel id");

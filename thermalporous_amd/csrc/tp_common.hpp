@@ -12,6 +12,7 @@
 struct ncclComm;
 
 namespace tp {
+struct LocalGroup;
 
 void set_error(const std::string &msg);
 
@@ -156,8 +157,11 @@ struct tp_ctx {
     hipGraphExec_t pc_graph = nullptr;
     uint64_t graph_epoch = 1, pc_graph_epoch = 0;
     uintptr_t pc_sig = 0;
-    // comm
+    // comm: RCCL communicator (one process per GPU) or an in-process slab group (several contexts on one GPU,
+    // used to validate the slab algorithm where only one GPU is available)
     ncclComm *comm = nullptr;
+    tp::LocalGroup *lgroup = nullptr;
+    bool dist = false;
     // multi-GPU stage 1: the pressure (and temperature) systems gathered on the global grid of every rank
     tp::GridDev gfull;
     tp::DBuf<double> gA00, gA01, gA10, gSm, gvec;   // operators: 7 planes each; gvec: work vectors

@@ -374,7 +374,7 @@ void decouple(tp_ctx *c) {
     if (c->At.n < (size_t)7 * npri * npri * nt) c->At.alloc((size_t)7 * npri * npri * nt);
     if (c->dcoef.n < (size_t)npri * nt) c->dcoef.alloc((size_t)npri * nt);
     const int ti = c->opt.decoup == 2;
-    if (ti && c->comm) halo_exchange(c, g, c->J.p, 7 * B * B, nt);   // column sums read neighbour rows
+    if (ti && c->dist) halo_exchange(c, g, c->J.p, 7 * B * B, nt);   // column sums read neighbour rows
     const dim3 gr = grid_for(g.nown), bl(256);
     if (B == 3) {
         hipLaunchKernelGGL(k_decoup_coef<3>, gr, bl, 0, c->stream, g, c->J.p, npri, ti, c->dcoef.p);

@@ -40,7 +40,7 @@ static void face_strengths(tp_ctx *c, double st[3]) {
                     acc[3 + a] += 1.0;
                 }
     }
-    if (c->comm) {
+    if (c->dist) {
         if (c->red_out.n < 6) c->red_out.alloc(64);
         TP_HIP(hipMemcpyAsync(c->red_out.p, acc, sizeof(acc), hipMemcpyHostToDevice, c->stream));
         allreduce_sum(c, c->red_out.p, 6);
@@ -59,7 +59,7 @@ void pc_setup(tp_ctx *c) {
     // single GPU: the AMG works on the slab (= whole grid).  Multi-GPU: stage 1 is NOT decomposed -- every
     // rank gathers the scalar stage-1 operators and runs the V-cycles on the global grid, so that the
     // preconditioner (and the iteration counts) are those of the single-GPU run; only stage 2 is bjacobi.
-    const GridDev gam = c->comm ? c->gfull : make_grid(c->g.n0, c->g.n1, c->g.n2, c->g.n2, 0);
+    const GridDev gam = c->dist ? c->gfull : make_grid(c->g.n0, c->g.n1, c->g.n2, c->g.n2, 0);
     if (!c->amg_p) {
         double st[3];
         face_strengths(c, st);         // coarsening schedule decided once; structure is static
@@ -78,7 +78,7 @@ void pc_setup(tp_ctx *c) {
     Sl.base = c->Sm.p;
     Sl.slot_stride = c->g.ntot;
     if (cptr) TP_REQUIRE(c->Sm.p, "pc_cptr needs the S~ operator (assemble with want_schur)");
-    if (c->comm) {
+    if (c->dist) {
         const size_t ng = (size_t)c->gfull.ntot;
         if (c->gA00.n < 7 * ng) {
             c->gA00.alloc(7 * ng);
@@ -130,7 +130,7 @@ void stage1_apply(tp_ctx *c, const double *x, double *y) {
         TP_REQUIRE(c->b == 3, "pc_cptr is a two-phase preconditioner");
         stage1_rhs(c, x, 1, r1);
     }
-    if (c->comm) {
+    if (c->dist) {
         // gathered global system: work vectors gr0, gr1, gy0, gy1, gt, gw on the global grid
         const GridDev &G = c->gfull;
         const long ng = G.ntot;
@@ -184,7 +184,7 @@ void pc_apply(tp_ctx *c, const double *x, double *y) {
     TP_REQUIRE(c->pc_ready, "pc_apply before pc_setup");
     static const bool use_graph = !(getenv("TP_GRAPH") && atoi(getenv("TP_GRAPH")) == 0);
     c->vcycles += c->opt.pc_kind == 1 ? 3 : 1;
-    if (!use_graph || c->comm) {
+    if (!use_graph || c->dist) {
         pc_apply_body(c, x, y);
         return;
     }
@@ -259,7 +259,7 @@ int fgmres(tp_ctx *c, const double *bvec, double *x, int *its_out, double *rnorm
             ensure_basis(j + 2);
             double *vj = c->V.p + (long)j * nv, *zj = c->Z.p + (long)j * nv, *w = c->V.p + (long)(j + 1) * nv;
             pc_apply(c, vj, zj);                                            // z_j = M^-1 v_j
-            if (c->comm) halo_exchange(c, g, zj, B, g.ntot);
+            if (c->dist) halo_exchange(c, g, zj, B, g.ntot);
             spmv_block(c, c->J.p, zj, w);                                   // w = J z_j
             orthogonalize(c, B, c->V.p, nv, j + 1, w, hcol.data());         // h = V^T w ; w -= V h ; ||w||^2
             const double hn = std::sqrt(hcol[j + 1]);
@@ -296,7 +296,7 @@ int fgmres(tp_ctx *c, const double *bvec, double *x, int *its_out, double *rnorm
         if (reason) { *its_out = its; *rnorm_out = res; return reason; }
         if (its >= maxit) { *its_out = its; *rnorm_out = res; return -3; }
         // restart: r = b - J x
-        if (c->comm) halo_exchange(c, g, x, B, g.ntot);
+        if (c->dist) halo_exchange(c, g, x, B, g.ntot);
         resid_block_cols(c, c->J.p, bvec, x, B, c->w2.p);
         beta = norm2(c, B, c->w2.p);
         rsrc = c->w2.p;
@@ -316,7 +316,7 @@ void newton(tp_ctx *c, tp_solve_info *info) {
     tp::DBuf<double> *dx = &c->dx;
     if (dx->n < (size_t)nv) dx->alloc(nv);
 
-    if (c->comm) halo_exchange(c, g, c->u.p, B, g.ntot);
+    if (c->dist) halo_exchange(c, g, c->u.p, B, g.ntot);
     assemble(c, true, schur);
     double fnorm = norm2(c, B, c->R.p);
     const double fnorm0 = fnorm;
@@ -332,7 +332,7 @@ void newton(tp_ctx *c, tp_solve_info *info) {
         lits += kits;
         if (kreason < 0) { reason = -3; break; }                 // SNES_DIVERGED_LINEAR_SOLVE
         vec_axpy_owned(c, B, -1.0, dx->p, c->u.p);               // basic line search, lambda = 1
-        if (c->comm) halo_exchange(c, g, c->u.p, B, g.ntot);
+        if (c->dist) halo_exchange(c, g, c->u.p, B, g.ntot);
         assemble(c, true, schur);
         ++nits;
         double nrm[3];

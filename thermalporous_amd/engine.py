@@ -55,6 +55,7 @@ class tp_solve_info(C.Structure):
 # every symbol include/thermalporous_hip.h declares (tests check that the library exports them all)
 API_SYMBOLS = (
     "tp_last_error", "tp_version", "tp_create", "tp_destroy", "tp_set_options", "tp_comm_unique_id", "tp_comm_init",
+    "tp_local_group_create", "tp_local_group_destroy", "tp_comm_init_local",
     "tp_set_field", "tp_finalize_fields", "tp_set_sources", "tp_set_state", "tp_get_state", "tp_set_old_state",
     "tp_set_dt", "tp_get_old_state", "tp_restore_state", "tp_saturation_range", "tp_clamp_saturation",
     "tp_residual", "tp_jacobian", "tp_get_residual", "tp_export_jacobian", "tp_export_schur",
@@ -109,7 +110,7 @@ def slab_range(gn2, rank, nranks):
 class HipEngine:
     """Same interface as oracle.engine.OracleEngine; all arithmetic on the GPU."""
 
-    def __init__(self, spec, opts=None, rank=0, nranks=1, device=None, comm_bootstrap=None):
+    def __init__(self, spec, opts=None, rank=0, nranks=1, device=None, comm_bootstrap=None, local_group=None):
         self.lib = load_library()
         self.spec = spec
         self.opts = dict(DEFAULT_OPTS)
@@ -131,9 +132,12 @@ class HipEngine:
         self._opt = self._make_options(self.opts)
         self.ctx = C.c_void_p()
         if device is None:
-            device = int(os.environ.get("LOCAL_RANK", "0")) if self.nranks > 1 else 0
+            device = int(os.environ.get("LOCAL_RANK", "0")) if (self.nranks > 1 and local_group is None) else 0
         self._ck(self.lib.tp_create(C.byref(g), C.byref(prm), C.byref(self._opt), int(device), C.byref(self.ctx)))
-        if self.nranks > 1:
+        if self.nranks > 1 and local_group is not None:
+            # N engines in N threads of this process sharing one GPU (validation of the slab algorithm)
+            self._ck(self.lib.tp_comm_init_local(self.ctx, local_group))
+        elif self.nranks > 1:
             if comm_bootstrap is None:
                 raise EngineError("multi-slab engine needs comm_bootstrap(make_id) -> 128-byte id")
             ident = comm_bootstrap(self._unique_id)
