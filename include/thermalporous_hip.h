@@ -77,6 +77,7 @@ typedef struct tp_options {
     int32_t ilu_t0;          /* tile extent along axis 0 (<= 0: the whole line) */
     int32_t amg_full_levels; /* V(nu,nu) on the first amg_full_levels levels ... */
     int32_t amg_coarse_pre, amg_coarse_post;  /* ... V(coarse_pre, coarse_post) below (coarse_post >= 1) */
+    int32_t amg_single;      /* 1: AMG operators/weights stored in fp32 (vectors and arithmetic stay fp64) */
 } tp_options;
 
 /* Result of one nonlinear solve (SNES iteration number / linear iterations / reason:

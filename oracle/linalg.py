@@ -185,11 +185,12 @@ class SemiAMG:
     """
 
     def __init__(self, n, strength, omega=0.8, min_cells=64, nu=1, max_levels=40, full_levels=99, coarse_pre=None,
-                 coarse_post=None):
+                 coarse_post=None, single=False):
         """V(nu,nu) on the first `full_levels` levels, V(coarse_pre, coarse_post) below (the coarse levels of
         the GPU cycle are launch-latency bound: dropping their pre-smoothing costs no Krylov iterations)."""
         self.n = tuple(n)
         self.omega, self.nu = omega, nu
+        self.single = bool(single)      # operators / weights / inverse diagonals stored in fp32 (GPU amg_single)
         self.full_levels = full_levels
         self.coarse_pre = nu if coarse_pre is None else coarse_pre
         self.coarse_post = nu if coarse_post is None else coarse_post
@@ -219,11 +220,11 @@ class SemiAMG:
         return -A[1 + 2 * a] / c, -A[2 + 2 * a] / c
 
     @staticmethod
-    def coarsen(A, a):
+    def coarsen(A, a, w=None):
         ax = 2 - a
         n = A.shape[1 + ax]
         nc = (n + 1) // 2
-        wm, wp = SemiAMG.weights(A, a)
+        wm, wp = w if w is not None else SemiAMG.weights(A, a)
         rho = A.sum(axis=0)
         ev = _axsl(ax, slice(0, n, 2))
 
@@ -249,13 +250,19 @@ class SemiAMG:
         Ac[0] = -Ac[1:].sum(axis=0) + rho[ev] + Pm * nb(rho, -1) + Pp * nb(rho, +1)
         return Ac, (wm, wp)
 
+    def _store(self, x):
+        return x.astype(np.float32).astype(np.float64) if self.single else x
+
     def setup(self, A):
-        self.levels = [A]
+        self.levels = [self._store(A)]
         self.W = []
         for a in self.sched:
-            Ac, w = self.coarsen(self.levels[-1], a)
-            self.levels.append(Ac)
+            A_l = self.levels[-1]
+            w = tuple(self._store(v) for v in self.weights(A_l, a))
+            Ac, _ = self.coarsen(A_l, a, w)
+            self.levels.append(self._store(Ac))
             self.W.append(w)
+        self.invd = [self._store(self.omega / l[0]) for l in self.levels]
         import scipy.sparse.linalg as spla
         M = to_csr(self.levels[-1][:, None, None])
         self.coarse = spla.splu(M.tocsc()) if M.shape[0] > 1 else None
@@ -295,8 +302,8 @@ class SemiAMG:
         e[odd] = wm[odd] * left + wp[odd] * right
         return e
 
-    def _smooth(self, A, b, x):
-        return x + self.omega * (b - spmv_scalar(A, x)) / A[0]
+    def _smooth(self, lvl, b, x):
+        return x + self.invd[lvl] * (b - spmv_scalar(self.levels[lvl], x))
 
     def vcycle(self, b, lvl=0):
         A = self.levels[lvl]
@@ -308,14 +315,14 @@ class SemiAMG:
         if pre == 0:
             x, r = np.zeros_like(b), b
         else:
-            x = self.omega * b / A[0]
+            x = self.invd[lvl] * b
             for _ in range(pre - 1):
-                x = self._smooth(A, b, x)
+                x = self._smooth(lvl, b, x)
             r = b - spmv_scalar(A, x)
         ec = self.vcycle(self.restrict(r, lvl), lvl + 1)
         x = x + self.prolong(ec, lvl, b.shape)
         for _ in range(post):
-            x = self._smooth(A, b, x)
+            x = self._smooth(lvl, b, x)
         return x
 
 
@@ -384,7 +391,7 @@ class TwoStagePC:
         self.slabs = slab_ranges(n[2], int(opts.get("nslabs", 1)))
         kw = dict(omega=opts["amg_omega"], min_cells=opts["amg_min_cells"], nu=opts["amg_nu"],
                   full_levels=opts.get("amg_full_levels", 99), coarse_pre=opts.get("amg_coarse_pre"),
-                  coarse_post=opts.get("amg_coarse_post"))
+                  coarse_post=opts.get("amg_coarse_post"), single=opts.get("amg_single", False))
 
         # coarsening schedule from the mean interior-face transmissibility per axis
         st = [float(np.mean(prob.TK[a][_lo(a)])) if n[a] > 1 else 0.0 for a in range(3)]

@@ -6,11 +6,17 @@ tile = eval(sys.argv[1]) if len(sys.argv) > 1 else None
 m = bench.make_model("c4")
 if tile:
     m.engine.set_options(ilu_tile=tile)
+if len(sys.argv) > 2:
+    m.engine.set_options(**eval(sys.argv[2]))
 m.start()
 t = time.time()
-for i in range(4):
-    print(m.step(), flush=True)
-print("4 steps %.3fs" % (time.time() - t), "failed", m.failed_solves)
+nsteps = int(os.environ.get("NSTEPS", "4"))
+tot = [0, 0]
+for i in range(nsteps):
+    r = m.step()
+    tot[0] += r[0]; tot[1] += r[1]
+print("its", tot, flush=True)
+print("steps %.3fs" % (time.time() - t), "failed", m.failed_solves)
 e = m.engine
 e.lib.tp_jacobian(e.ctx); e.pc_setup()
 for w, nm in enumerate(["spmv", "ilu_solve", "amg_vcycle", "assembly", "pc_apply"]):

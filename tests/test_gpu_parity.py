@@ -39,6 +39,8 @@ CASES = [
     ("c4_1ph_3d", cases.c4_spe10_3d, dict(Nx=7, Ny=13, Nz=9, nphase=1), dict(pc="cpr", decoup="TI")),
     ("c4_2ph_3d_cprQI", cases.c4_spe10_3d, dict(Nx=9, Ny=10, Nz=5, nphase=2), dict(pc="cpr", decoup="QI")),
     ("c4_2ph_3d_tiles", cases.c4_spe10_3d, dict(Nx=11, Ny=13, Nz=17, nphase=2), dict(pc="cptr", ilu_tile=(5, 4, 7))),
+    ("c4_2ph_3d_fp32amg", cases.c4_spe10_3d, dict(Nx=9, Ny=14, Nz=8, nphase=2), dict(pc="cptr", amg_single=True)),
+    ("c4_2ph_3d_v22", cases.c4_spe10_3d, dict(Nx=9, Ny=14, Nz=8, nphase=2), dict(pc="cptr", amg_full_levels=99)),
 ]
 
 
@@ -100,14 +102,17 @@ def test_linear_stages_parity(name, builder, kw, opts):
     h.ilu_solve("x", "y")
     assert rel2(h.vec_get("y"), o.pc.ilu.solve(x)) < 1e-10
     h.amg_vcycle(0, "x", 0, "y", 0)
-    assert rel2(h.vec_get("y")[0], o.pc.amg_p.vcycle(x[0])) < 1e-10
+    # amg_single: both sides round the stored operators to fp32 identically; the double-precision
+    # intermediates differ by FMA contraction before that rounding, so a few entries round differently
+    vtol = 1e-6 if opts.get("amg_single") else 1e-10
+    assert rel2(h.vec_get("y")[0], o.pc.amg_p.vcycle(x[0])) < vtol
     if schur:
         h.amg_vcycle(1, "x", 1, "y", 1)
-        assert rel2(h.vec_get("y")[1], o.pc.amg_T.vcycle(x[1])) < 1e-10
+        assert rel2(h.vec_get("y")[1], o.pc.amg_T.vcycle(x[1])) < vtol
     h.stage1_apply("x", "y")
-    assert rel2(h.vec_get("y"), o.pc.stage1(x)) < 1e-10
+    assert rel2(h.vec_get("y"), o.pc.stage1(x)) < vtol
     h.pc_apply("x", "y")
-    assert rel2(h.vec_get("y"), o.pc.apply(x)) < 1e-10
+    assert rel2(h.vec_get("y"), o.pc.apply(x)) < vtol
     # FGMRES on J d = F
     F = o.residual()
     h.residual()

@@ -27,6 +27,16 @@
 
 namespace tp {
 
+// Operator storage type R: double, or float (amg_single: the AMG is only a preconditioner inside the flexible
+// Krylov method, so its operators, weights and inverse diagonals can be stored in fp32 -- 7 of the ~11 planes
+// every smoothing sweep streams -- while all vectors and all arithmetic stay fp64).
+template <class R>
+struct StencilT {
+    R *base;
+    long slot_stride;
+    __host__ __device__ const R *slot(int s) const { return base + (long)s * slot_stride; }
+};
+
 static inline dim3 grid_for(long n, int bs = 256) { return dim3((unsigned)((n + bs - 1) / bs)); }
 
 __device__ __forceinline__ void cell_ijk(const GridDev &g, long tid, int &i0, int &i1, int &i2) {
@@ -38,24 +48,25 @@ __device__ __forceinline__ void cell_ijk(const GridDev &g, long tid, int &i0, in
 
 // ---- set-up kernels --------------------------------------------------------------------------------
 // interpolation weights of every cell w.r.t. axis a (only odd cells are used) + invd = omega/diag
-__global__ void k_amg_weights(GridDev g, Stencil A, int axis, double omega, double *wm, double *wp, double *invd) {
+template <class R>
+__global__ void k_amg_weights(GridDev g, StencilT<R> A, int axis, double omega, R *wm, R *wp, R *invd) {
     const long tid = (long)blockIdx.x * blockDim.x + threadIdx.x;
     if (tid >= g.nown) return;
     const long c = g.np + tid;
     const double a0 = A.slot(0)[c];
-    invd[c] = omega / a0;
+    invd[c] = (R)(omega / a0);
     if (axis < 0) return;
     double cc = a0;
 #pragma unroll
     for (int s = 1; s < 7; ++s)
         if ((s - 1) / 2 != axis) cc += A.slot(s)[c];
-    wm[c] = -A.slot(1 + 2 * axis)[c] / cc;
-    wp[c] = -A.slot(2 + 2 * axis)[c] / cc;
+    wm[c] = (R)(-A.slot(1 + 2 * axis)[c] / cc);
+    wp[c] = (R)(-A.slot(2 + 2 * axis)[c] / cc);
 }
 
 // coarse operator: one thread per coarse cell
-__global__ void k_amg_coarsen(GridDev gf, GridDev gc, Stencil A, int axis, const double *wm, const double *wp,
-                              double *Ac) {
+template <class R>
+__global__ void k_amg_coarsen(GridDev gf, GridDev gc, StencilT<R> A, int axis, const R *wm, const R *wp, R *Ac) {
     const long tid = (long)blockIdx.x * blockDim.x + threadIdx.x;
     if (tid >= gc.nown) return;
     int I[3];
@@ -89,11 +100,12 @@ __global__ void k_amg_coarsen(GridDev gf, GridDev gc, Stencil A, int axis, const
     }
     out[0] = -offsum + rho_f + Pm * rho_m + Pp * rho_p;
 #pragma unroll
-    for (int s = 0; s < 7; ++s) Ac[(long)s * gc.ntot + cc] = out[s];
+    for (int s = 0; s < 7; ++s) Ac[(long)s * gc.ntot + cc] = (R)out[s];
 }
 
 // coarsest grid: dense inverse by Gauss-Jordan in one workgroup (diagonally dominant: no pivoting)
-__global__ void k_amg_dense_inverse(GridDev g, Stencil A, int n, double *M, double *Minv) {
+template <class R>
+__global__ void k_amg_dense_inverse(GridDev g, StencilT<R> A, int n, double *M, double *Minv) {
     const long off[7] = {0, -1, 1, -(long)g.n0, (long)g.n0, -g.np, g.np};
     for (int e = threadIdx.x; e < n * n; e += blockDim.x) { M[e] = 0.0; Minv[e] = (e / n == e % n) ? 1.0 : 0.0; }
     __syncthreads();
@@ -129,10 +141,11 @@ __global__ void k_amg_dense_inverse(GridDev g, Stencil A, int n, double *M, doub
 }
 
 // ---- per-cell building blocks of the cycle (shared by the per-level kernels and the tail kernel) ------
-struct LevelDev {
+template <class R>
+struct LevelDevT {
     GridDev g;
-    Stencil op;
-    const double *invd, *wm, *wp;
+    StencilT<R> op;
+    const R *invd, *wm, *wp;
     double *b, *x, *x2, *e;
     int axis;
     int pre, post;           // smoothing sweeps of this level: V(pre, post), post >= 1
@@ -144,7 +157,8 @@ __device__ __forceinline__ void nb_offsets(const GridDev &g, long (&off)[7]) {
 }
 
 // two damped-Jacobi sweeps from a zero initial guess:  x1 = invd b ;  x2 = x1 + invd (b - A x1)
-__device__ __forceinline__ double pre2_cell(const LevelDev &L, const double *__restrict__ b, long tid) {
+template <class R>
+__device__ __forceinline__ double pre2_cell(const LevelDevT<R> &L, const double *__restrict__ b, long tid) {
     const long c = L.g.np + tid;
     long off[7];
     nb_offsets(L.g, off);
@@ -158,7 +172,8 @@ __device__ __forceinline__ double pre2_cell(const LevelDev &L, const double *__r
     return x1 + L.invd[c] * (b[c] - s);
 }
 
-__device__ __forceinline__ double jacobi_cell(const LevelDev &L, const double *__restrict__ b,
+template <class R>
+__device__ __forceinline__ double jacobi_cell(const LevelDevT<R> &L, const double *__restrict__ b,
                                               const double *__restrict__ x, long tid) {
     const long c = L.g.np + tid;
     long off[7];
@@ -169,7 +184,8 @@ __device__ __forceinline__ double jacobi_cell(const LevelDev &L, const double *_
     return x[c] + L.invd[c] * (b[c] - s);
 }
 
-__device__ __forceinline__ double resid_at(const LevelDev &L, const double *__restrict__ b,
+template <class R>
+__device__ __forceinline__ double resid_at(const LevelDevT<R> &L, const double *__restrict__ b,
                                            const double *__restrict__ x, long c) {
     long off[7];
     nb_offsets(L.g, off);
@@ -180,7 +196,8 @@ __device__ __forceinline__ double resid_at(const LevelDev &L, const double *__re
 }
 
 // (P^T (b - A x)) at coarse cell tidc
-__device__ __forceinline__ double resid_restrict_cell(const LevelDev &Lf, const GridDev &gc,
+template <class R>
+__device__ __forceinline__ double resid_restrict_cell(const LevelDevT<R> &Lf, const GridDev &gc,
                                                       const double *__restrict__ b, const double *__restrict__ x,
                                                       long tidc) {
     int I[3];
@@ -199,7 +216,8 @@ __device__ __forceinline__ double resid_restrict_cell(const LevelDev &Lf, const 
 }
 
 // (P^T r) at coarse cell tidc, r given as a vector
-__device__ __forceinline__ double restrict_cell(const LevelDev &Lf, const GridDev &gc, const double *__restrict__ r,
+template <class R>
+__device__ __forceinline__ double restrict_cell(const LevelDevT<R> &Lf, const GridDev &gc, const double *__restrict__ r,
                                                 long tidc) {
     int I[3];
     cell_ijk(gc, tidc, I[0], I[1], I[2]);
@@ -217,7 +235,8 @@ __device__ __forceinline__ double restrict_cell(const LevelDev &Lf, const GridDe
 }
 
 // (P ec) at fine cell (F0,F1,F2)
-__device__ __forceinline__ double prolong_at(const LevelDev &Lf, const GridDev &gc, const double *__restrict__ ec,
+template <class R>
+__device__ __forceinline__ double prolong_at(const LevelDevT<R> &Lf, const GridDev &gc, const double *__restrict__ ec,
                                              int F0, int F1, int F2) {
     const int a = Lf.axis;
     const int Fa = a == 0 ? F0 : (a == 1 ? F1 : F2);
@@ -235,7 +254,8 @@ __device__ __forceinline__ double prolong_at(const LevelDev &Lf, const GridDev &
 
 // coarse-grid correction fused with the first post-smoothing sweep:
 //   x' = x + P ec ;  out = x' + invd (b - A x')
-__device__ __forceinline__ double prolong_jacobi_cell(const LevelDev &Lf, const GridDev &gc,
+template <class R>
+__device__ __forceinline__ double prolong_jacobi_cell(const LevelDevT<R> &Lf, const GridDev &gc,
                                                       const double *__restrict__ b, const double *x,
                                                       const double *__restrict__ ec, long tid) {
     const GridDev &g = Lf.g;
@@ -256,46 +276,53 @@ __device__ __forceinline__ double prolong_jacobi_cell(const LevelDev &Lf, const 
 }
 
 // ---- per-level kernels (big levels) -----------------------------------------------------------------
-__global__ __launch_bounds__(256) void k_amg_pre(LevelDev L, const double *b, int two, double *out) {
-    const long tid = (long)blockIdx.x * blockDim.x + threadIdx.x;
+template <class R>
+__global__ __launch_bounds__(256) void k_amg_pre(LevelDevT<R> L, const double *b, int two, double *out) {
+    const long tid = xcd_tid();
     if (tid >= L.g.nown) return;
     const long c = L.g.np + tid;
     out[c] = two ? pre2_cell(L, b, tid) : L.invd[c] * b[c];
 }
-__global__ __launch_bounds__(256) void k_amg_jacobi(LevelDev L, const double *b, const double *x, double *out) {
-    const long tid = (long)blockIdx.x * blockDim.x + threadIdx.x;
+template <class R>
+__global__ __launch_bounds__(256) void k_amg_jacobi(LevelDevT<R> L, const double *b, const double *x, double *out) {
+    const long tid = xcd_tid();
     if (tid >= L.g.nown) return;
     out[L.g.np + tid] = jacobi_cell(L, b, x, tid);
 }
-__global__ __launch_bounds__(256) void k_amg_resid_restrict(LevelDev Lf, GridDev gc, const double *b,
+template <class R>
+__global__ __launch_bounds__(256) void k_amg_resid_restrict(LevelDevT<R> Lf, GridDev gc, const double *b,
                                                             const double *x, double *rc) {
-    const long tid = (long)blockIdx.x * blockDim.x + threadIdx.x;
+    const long tid = xcd_tid();
     if (tid >= gc.nown) return;
     rc[gc.np + tid] = resid_restrict_cell(Lf, gc, b, x, tid);
 }
-__global__ __launch_bounds__(256) void k_amg_prolong_jacobi(LevelDev Lf, GridDev gc, const double *b,
+template <class R>
+__global__ __launch_bounds__(256) void k_amg_prolong_jacobi(LevelDevT<R> Lf, GridDev gc, const double *b,
                                                             const double *x, const double *ec, double *out) {
-    const long tid = (long)blockIdx.x * blockDim.x + threadIdx.x;
+    const long tid = xcd_tid();
     if (tid >= Lf.g.nown) return;
     out[Lf.g.np + tid] = prolong_jacobi_cell(Lf, gc, b, x, ec, tid);
 }
 
 // unfused variants for the top levels, where the fused kernels are issue-bound rather than HBM-bound
-__global__ __launch_bounds__(256) void k_amg_resid(LevelDev L, const double *__restrict__ b,
+template <class R>
+__global__ __launch_bounds__(256) void k_amg_resid(LevelDevT<R> L, const double *__restrict__ b,
                                                    const double *__restrict__ x, double *__restrict__ r) {
-    const long tid = (long)blockIdx.x * blockDim.x + threadIdx.x;
+    const long tid = xcd_tid();
     if (tid >= L.g.nown) return;
     r[L.g.np + tid] = resid_at(L, b, x, L.g.np + tid);
 }
-__global__ __launch_bounds__(256) void k_amg_restrict(LevelDev Lf, GridDev gc, const double *__restrict__ r,
+template <class R>
+__global__ __launch_bounds__(256) void k_amg_restrict(LevelDevT<R> Lf, GridDev gc, const double *__restrict__ r,
                                                       double *__restrict__ rc) {
-    const long tid = (long)blockIdx.x * blockDim.x + threadIdx.x;
+    const long tid = xcd_tid();
     if (tid >= gc.nown) return;
     rc[gc.np + tid] = restrict_cell(Lf, gc, r, tid);
 }
-__global__ __launch_bounds__(256) void k_amg_prolong_add(LevelDev Lf, GridDev gc, const double *__restrict__ ec,
+template <class R>
+__global__ __launch_bounds__(256) void k_amg_prolong_add(LevelDevT<R> Lf, GridDev gc, const double *__restrict__ ec,
                                                          double *x) {
-    const long tid = (long)blockIdx.x * blockDim.x + threadIdx.x;
+    const long tid = xcd_tid();
     if (tid >= Lf.g.nown) return;
     int i0, i1, i2;
     cell_ijk(Lf.g, tid, i0, i1, i2);
@@ -303,23 +330,24 @@ __global__ __launch_bounds__(256) void k_amg_prolong_add(LevelDev Lf, GridDev gc
 }
 
 // ---- the tail: all small levels in one workgroup --------------------------------------------------------
-__global__ __launch_bounds__(1024) void k_amg_tail(const LevelDev *lv, int l0, int nlev, int nu, int ncoarse,
+template <class R>
+__global__ __launch_bounds__(1024) void k_amg_tail(const LevelDevT<R> *lv, int l0, int nlev, int nu, int ncoarse,
                                                    const double *Minv, const double *b_top, double *e_top) {
     const int T = blockDim.x, t = threadIdx.x;
     // level descriptors live in LDS: every phase below starts with LDS reads, not a global round trip
-    static_assert(sizeof(LevelDev) % sizeof(long) == 0, "LevelDev must be a whole number of words");
-    __shared__ long slv_raw[40 * sizeof(LevelDev) / sizeof(long)];
+    static_assert(sizeof(LevelDevT<R>) % sizeof(long) == 0, "LevelDev must be a whole number of words");
+    __shared__ long slv_raw[40 * sizeof(LevelDevT<R>) / sizeof(long)];
     {
-        const int wpl = (int)(sizeof(LevelDev) / sizeof(long));
+        const int wpl = (int)(sizeof(LevelDevT<R>) / sizeof(long));
         const long *src = reinterpret_cast<const long *>(lv);
         for (int i = l0 * wpl + t; i < nlev * wpl; i += T) slv_raw[i] = src[i];
         __syncthreads();
     }
-    lv = reinterpret_cast<const LevelDev *>(slv_raw);
+    lv = reinterpret_cast<const LevelDevT<R> *>(slv_raw);
     (void)nu;
     // down-sweep
     for (int l = l0; l < nlev - 1; ++l) {
-        const LevelDev L = lv[l];
+        const LevelDevT<R> L = lv[l];
         const GridDev gc = lv[l + 1].g;
         const double *b = (l == l0) ? b_top : L.b;
         double *rc = lv[l + 1].b;
@@ -342,7 +370,7 @@ __global__ __launch_bounds__(1024) void k_amg_tail(const LevelDev *lv, int l0, i
     }
     // coarsest grid: dense solve
     {
-        const LevelDev Lc = lv[nlev - 1];
+        const LevelDevT<R> Lc = lv[nlev - 1];
         const double *b = (nlev - 1 == l0) ? b_top : Lc.b;
         double *e = (nlev - 1 == l0) ? e_top : Lc.e;
         for (int r = t; r < ncoarse; r += T) {
@@ -354,7 +382,7 @@ __global__ __launch_bounds__(1024) void k_amg_tail(const LevelDev *lv, int l0, i
     }
     // up-sweep
     for (int l = nlev - 2; l >= l0; --l) {
-        const LevelDev L = lv[l];
+        const LevelDevT<R> L = lv[l];
         const GridDev gc = lv[l + 1].g;
         const double *b = (l == l0) ? b_top : L.b;
         double *out = (l == l0) ? e_top : L.e;
@@ -392,15 +420,18 @@ static std::vector<int> schedule(const int n_[3], const double strength[3], int 
     return sched;
 }
 
-static LevelDev dev_of(const AmgLevel *L, int level, const tp_options &o) {
-    LevelDev d;
+template <class R>
+static LevelDevT<R> dev_of(const AmgLevel *L, int level, const tp_options &o) {
+    LevelDevT<R> d;
     const int nu = std::max(1, o.amg_nu);
     const bool full = level < o.amg_full_levels;
     d.pre = full ? nu : std::max(0, o.amg_coarse_pre);
     d.post = full ? nu : std::max(1, o.amg_coarse_post);
     d.pad_ = 0;
-    d.g = L->g; d.op = L->op;
-    d.invd = L->invd.p; d.wm = L->wm.p; d.wp = L->wp.p;
+    d.g = L->g;
+    d.op.base = (R *)L->op.base;
+    d.op.slot_stride = L->op.slot_stride;
+    d.invd = (const R *)L->invd.p; d.wm = (const R *)L->wm.p; d.wp = (const R *)L->wp.p;
     d.b = L->b.p; d.x = L->x.p; d.x2 = L->x2.p; d.e = L->e.p;
     d.axis = L->axis;
     return d;
@@ -409,6 +440,7 @@ static LevelDev dev_of(const AmgLevel *L, int level, const tp_options &o) {
 void amg_build(tp_ctx *c, Amg *&amg, const GridDev &g0, const double strength[3]) {
     delete amg;
     amg = new Amg();
+    amg->single = c->opt.amg_single != 0;
     const int n[3] = {g0.n0, g0.n1, g0.n2};
     amg->sched = schedule(n, strength, std::max(1, c->opt.amg_min_cells));
     int m[3] = {n[0], n[1], n[2]};
@@ -417,7 +449,8 @@ void amg_build(tp_ctx *c, Amg *&amg, const GridDev &g0, const double strength[3]
         // every level is a box with dead halo planes (multi-GPU: the hierarchy lives on the gathered global grid)
         L->g = make_grid(m[0], m[1], m[2], m[2], 0);
         const size_t nt = (size_t)L->g.ntot;
-        if (l > 0) {
+        // operator/weight buffers are sized for doubles and hold floats when amg_single (slot stride in elements)
+        if (l > 0 || amg->single) {
             L->A.alloc(7 * nt);
             L->op.base = L->A.p;
             L->op.slot_stride = (long)nt;
@@ -440,36 +473,60 @@ void amg_build(tp_ctx *c, Amg *&amg, const GridDev &g0, const double strength[3]
     amg->tail_level = (int)amg->lv.size() - 1;
     for (size_t l = 0; l < amg->lv.size(); ++l)
         if (amg->lv[l]->g.nown <= tail_cells) { amg->tail_level = (int)l; break; }
-    amg->lvdev.alloc(amg->lv.size() * sizeof(LevelDev));
+    amg->lvdev.alloc(amg->lv.size() * sizeof(LevelDevT<double>));
 }
 
-void amg_setup(tp_ctx *c, Amg *amg, const Stencil &A0) {
+// level-0 operator: double stencil view of the Jacobian -> storage type R
+template <class R>
+__global__ void k_amg_import(GridDev g, Stencil A0, R *out) {
+    const long tid = (long)blockIdx.x * blockDim.x + threadIdx.x;
+    if (tid >= g.nown) return;
+    const long c = g.np + tid;
+#pragma unroll
+    for (int s = 0; s < 7; ++s) out[(long)s * g.ntot + c] = (R)A0.slot(s)[c];
+}
+
+template <class R>
+static void setup_impl(tp_ctx *c, Amg *amg, const Stencil &A0) {
     AmgLevel *L0 = amg->lv[0];
-    L0->op = A0;
+    if (sizeof(R) == sizeof(double)) {
+        L0->op = A0;                     // zero-copy view of the Jacobian planes
+    } else {
+        hipLaunchKernelGGL(k_amg_import<R>, grid_for(L0->g.nown), dim3(256), 0, c->stream, L0->g, A0, (R *)L0->A.p);
+        L0->op.base = L0->A.p;
+        L0->op.slot_stride = L0->g.ntot;
+    }
     for (size_t l = 0; l < amg->lv.size(); ++l) {
         AmgLevel *L = amg->lv[l];
-        hipLaunchKernelGGL(k_amg_weights, grid_for(L->g.nown), dim3(256), 0, c->stream, L->g, L->op, L->axis,
-                           c->opt.amg_omega, L->wm.p, L->wp.p, L->invd.p);
+        const StencilT<R> op{(R *)L->op.base, L->op.slot_stride};
+        hipLaunchKernelGGL(k_amg_weights<R>, grid_for(L->g.nown), dim3(256), 0, c->stream, L->g, op, L->axis,
+                           c->opt.amg_omega, (R *)L->wm.p, (R *)L->wp.p, (R *)L->invd.p);
         if (L->axis >= 0) {
             AmgLevel *Lc = amg->lv[l + 1];
-            hipLaunchKernelGGL(k_amg_coarsen, grid_for(Lc->g.nown), dim3(256), 0, c->stream, L->g, Lc->g, L->op,
-                               L->axis, L->wm.p, L->wp.p, Lc->A.p);
+            hipLaunchKernelGGL(k_amg_coarsen<R>, grid_for(Lc->g.nown), dim3(256), 0, c->stream, L->g, Lc->g, op, L->axis,
+                               (const R *)L->wm.p, (const R *)L->wp.p, (R *)Lc->A.p);
         }
     }
     AmgLevel *Lc = amg->lv.back();
     const int n = amg->ncoarse;
-    hipLaunchKernelGGL(k_amg_dense_inverse, dim3(1), dim3(256), 0, c->stream, Lc->g, Lc->op, n, amg->coarse_inv.p,
+    const StencilT<R> opc{(R *)Lc->op.base, Lc->op.slot_stride};
+    hipLaunchKernelGGL(k_amg_dense_inverse<R>, dim3(1), dim3(256), 0, c->stream, Lc->g, opc, n, amg->coarse_inv.p,
                        amg->coarse_inv.p + (size_t)n * n);
-    std::vector<LevelDev> h;
-    for (size_t l = 0; l < amg->lv.size(); ++l) h.push_back(dev_of(amg->lv[l], (int)l, c->opt));
-    amg->lvhost.assign((const char *)h.data(), (const char *)h.data() + h.size() * sizeof(LevelDev));
+    std::vector<LevelDevT<R>> h;
+    for (size_t l = 0; l < amg->lv.size(); ++l) h.push_back(dev_of<R>(amg->lv[l], (int)l, c->opt));
+    amg->lvhost.assign((const char *)h.data(), (const char *)h.data() + h.size() * sizeof(LevelDevT<R>));
     TP_HIP(hipMemcpyAsync(amg->lvdev.p, amg->lvhost.data(), amg->lvhost.size(), hipMemcpyHostToDevice, c->stream));
     TP_HIP(hipGetLastError());
 }
 
-void amg_vcycle(tp_ctx *c, Amg *amg, const double *b, double *x) {
-    TP_REQUIRE(amg && !amg->lv.empty(), "AMG not set up");
-    TP_REQUIRE(x != amg->lv[0]->x.p && x != amg->lv[0]->x2.p && b != x, "aliasing in amg_vcycle");
+void amg_setup(tp_ctx *c, Amg *amg, const Stencil &A0) {
+    static_assert(sizeof(LevelDevT<float>) == sizeof(LevelDevT<double>), "descriptor size");
+    if (amg->single) setup_impl<float>(c, amg, A0);
+    else setup_impl<double>(c, amg, A0);
+}
+
+template <class R>
+static void vcycle_impl(tp_ctx *c, Amg *amg, const double *b, double *x) {
     const int nlev = (int)amg->lv.size(), lt = amg->tail_level;
     const dim3 bl(256);
     std::vector<double *> xs(nlev, nullptr);       // pre-smoothed iterate of each big level (null: none)
@@ -477,25 +534,27 @@ void amg_vcycle(tp_ctx *c, Amg *amg, const double *b, double *x) {
     for (int l = 0; l < lt; ++l) {
         AmgLevel *L = amg->lv[l];
         AmgLevel *Lc = amg->lv[l + 1];
-        const LevelDev Ld = dev_of(L, l, c->opt);
+        const LevelDevT<R> Ld = dev_of<R>(L, l, c->opt);
         const double *bl_ = (l == 0) ? b : L->b.p;
-        const dim3 gr = grid_for(L->g.nown);
+        const dim3 gr = xcd_grid(L->g.nown);
         if (Ld.pre == 0) {                          // V(0,post): residual = b
-            hipLaunchKernelGGL(k_amg_restrict, grid_for(Lc->g.nown), bl, 0, c->stream, Ld, Lc->g, bl_, Lc->b.p);
+            hipLaunchKernelGGL(k_amg_restrict<R>, xcd_grid(Lc->g.nown), bl, 0, c->stream, Ld, Lc->g, bl_, Lc->b.p);
             continue;
         }
         double *cur = L->x.p, *oth = L->x2.p;
-        hipLaunchKernelGGL(k_amg_pre, gr, bl, 0, c->stream, Ld, bl_, Ld.pre >= 2 ? 1 : 0, cur);
+        hipLaunchKernelGGL(k_amg_pre<R>, gr, bl, 0, c->stream, Ld, bl_, Ld.pre >= 2 ? 1 : 0, cur);
         for (int k = 2; k < Ld.pre; ++k) {
-            hipLaunchKernelGGL(k_amg_jacobi, gr, bl, 0, c->stream, Ld, bl_, cur, oth);
+            hipLaunchKernelGGL(k_amg_jacobi<R>, gr, bl, 0, c->stream, Ld, bl_, (const double *)cur, oth);
             std::swap(cur, oth);
         }
         xs[l] = cur;
         if (L->g.nown >= amg->fuse_below) {
-            hipLaunchKernelGGL(k_amg_resid, gr, bl, 0, c->stream, Ld, bl_, cur, oth);
-            hipLaunchKernelGGL(k_amg_restrict, grid_for(Lc->g.nown), bl, 0, c->stream, Ld, Lc->g, oth, Lc->b.p);
+            hipLaunchKernelGGL(k_amg_resid<R>, gr, bl, 0, c->stream, Ld, bl_, (const double *)cur, oth);
+            hipLaunchKernelGGL(k_amg_restrict<R>, xcd_grid(Lc->g.nown), bl, 0, c->stream, Ld, Lc->g, (const double *)oth,
+                               Lc->b.p);
         } else {
-            hipLaunchKernelGGL(k_amg_resid_restrict, grid_for(Lc->g.nown), bl, 0, c->stream, Ld, Lc->g, bl_, cur, Lc->b.p);
+            hipLaunchKernelGGL(k_amg_resid_restrict<R>, xcd_grid(Lc->g.nown), bl, 0, c->stream, Ld, Lc->g, bl_,
+                               (const double *)cur, Lc->b.p);
         }
     }
     // the tail: every level from lt down to the coarsest and back, one launch
@@ -504,32 +563,40 @@ void amg_vcycle(tp_ctx *c, Amg *amg, const double *b, double *x) {
         const double *bt = (lt == 0) ? b : Lt->b.p;
         double *et = (lt == 0) ? x : Lt->e.p;
         const int n = amg->ncoarse;
-        hipLaunchKernelGGL(k_amg_tail, dim3(1), dim3(1024), 0, c->stream, (const LevelDev *)amg->lvdev.p, lt, nlev,
-                           c->opt.amg_nu, n, amg->coarse_inv.p + (size_t)n * n, bt, et);
+        hipLaunchKernelGGL(k_amg_tail<R>, dim3(1), dim3(1024), 0, c->stream, (const LevelDevT<R> *)amg->lvdev.p, lt, nlev,
+                           c->opt.amg_nu, n, (const double *)(amg->coarse_inv.p + (size_t)n * n), bt, et);
     }
     // up-sweep over the big levels
     for (int l = lt - 1; l >= 0; --l) {
         AmgLevel *L = amg->lv[l];
         AmgLevel *Lc = amg->lv[l + 1];
-        const LevelDev Ld = dev_of(L, l, c->opt);
+        const LevelDevT<R> Ld = dev_of<R>(L, l, c->opt);
         const double *bl_ = (l == 0) ? b : L->b.p;
         double *out = (l == 0) ? x : L->e.p;
-        const dim3 gr = grid_for(L->g.nown);
+        const dim3 gr = xcd_grid(L->g.nown);
         double *src = xs[l];
         double *dst = (Ld.post == 1) ? out : (src == L->x.p ? L->x2.p : L->x.p);
         if (src && L->g.nown >= amg->fuse_below) {
-            hipLaunchKernelGGL(k_amg_prolong_add, gr, bl, 0, c->stream, Ld, Lc->g, Lc->e.p, src);
-            hipLaunchKernelGGL(k_amg_jacobi, gr, bl, 0, c->stream, Ld, bl_, src, dst);
+            hipLaunchKernelGGL(k_amg_prolong_add<R>, gr, bl, 0, c->stream, Ld, Lc->g, (const double *)Lc->e.p, src);
+            hipLaunchKernelGGL(k_amg_jacobi<R>, gr, bl, 0, c->stream, Ld, bl_, (const double *)src, dst);
         } else {
-            hipLaunchKernelGGL(k_amg_prolong_jacobi, gr, bl, 0, c->stream, Ld, Lc->g, bl_, (const double *)src, Lc->e.p, dst);
+            hipLaunchKernelGGL(k_amg_prolong_jacobi<R>, gr, bl, 0, c->stream, Ld, Lc->g, bl_, (const double *)src,
+                               (const double *)Lc->e.p, dst);
         }
         for (int k = 1; k < Ld.post; ++k) {
             src = dst;
             dst = (k == Ld.post - 1) ? out : (src == L->x.p ? L->x2.p : L->x.p);
-            hipLaunchKernelGGL(k_amg_jacobi, gr, bl, 0, c->stream, Ld, bl_, src, dst);
+            hipLaunchKernelGGL(k_amg_jacobi<R>, gr, bl, 0, c->stream, Ld, bl_, (const double *)src, dst);
         }
     }
     TP_HIP(hipGetLastError());
+}
+
+void amg_vcycle(tp_ctx *c, Amg *amg, const double *b, double *x) {
+    TP_REQUIRE(amg && !amg->lv.empty(), "AMG not set up");
+    TP_REQUIRE(x != amg->lv[0]->x.p && x != amg->lv[0]->x2.p && b != x, "aliasing in amg_vcycle");
+    if (amg->single) vcycle_impl<float>(c, amg, b, x);
+    else vcycle_impl<double>(c, amg, b, x);
 }
 
 }  // namespace tp

@@ -145,7 +145,7 @@ struct AsmArgs {
 template <int NPH, bool JAC, bool SCHUR>
 __global__ __launch_bounds__(256) void k_assemble(AsmArgs a) {
     constexpr int B = NPH + 1;
-    const long tid = (long)blockIdx.x * blockDim.x + threadIdx.x;
+    const long tid = xcd_tid();
     const GridDev &g = a.g;
     if (tid >= g.nown) return;
     const long c = g.np + tid;
@@ -445,7 +445,7 @@ void assemble(tp_ctx *c, bool want_jac, bool want_schur) {
     a.Vdt = c->vol / c->dt;
     a.R = c->R.p; a.J = c->J.p; a.Sm = c->Sm.p;
     if (want_schur) TP_REQUIRE(c->Sm.p, "S~ storage not allocated");
-    const dim3 gr = grid_for(g.nown), bl(256);
+    const dim3 gr = xcd_grid(g.nown), bl(256);
 #define LAUNCH(NPH, JAC, SCH) hipLaunchKernelGGL((k_assemble<NPH, JAC, SCH>), gr, bl, 0, c->stream, a)
     if (c->nph == 2) {
         if (!want_jac) LAUNCH(2, false, false);

@@ -51,6 +51,23 @@ inline GridDev make_grid(int n0, int n1, int n2, int gn2, int off2) {
     return g;
 }
 
+// XCD-aware block -> cell-range mapping (cdna_hip_programming.md T1): workgroups are dealt round-robin over
+// the 8 XCDs, each with its own L2.  Remapping block b to chunk (b % 8)*(nblocks/8) + b/8 gives every XCD
+// one contiguous eighth of the cell range, so the stencil's neighbour reads (x at c +- 1, +- n0, +- n0*n1)
+// hit in that XCD's L2 instead of being fetched once per XCD.  Pure performance: any placement is correct.
+// Grids launched with xcd_grid() have a multiple of 8 blocks; the kernel bounds-checks the cell index.
+#if defined(__HIPCC__)
+__device__ __forceinline__ long xcd_tid() {
+    const unsigned nb = gridDim.x, b = blockIdx.x;
+    const unsigned rb = (b & 7u) * (nb >> 3) + (b >> 3);
+    return (long)rb * blockDim.x + threadIdx.x;
+}
+#endif
+inline dim3 xcd_grid(long n, int bs = 256) {
+    const long nb = (n + bs - 1) / bs;
+    return dim3((unsigned)(((nb + 7) / 8) * 8));
+}
+
 // Scalar 7-point stencil operator: slot s lives at base + s*slot_stride (doubles).
 struct Stencil {
     double *base = nullptr;
@@ -103,6 +120,7 @@ struct Amg {
     std::vector<AmgLevel *> lv;
     DBuf<double> coarse_inv;   // dense inverse on the coarsest grid
     int ncoarse = 0;
+    bool single = false;       // operators / weights / inverse diagonals stored in fp32
     int tail_level = 0;        // first level handled by the single-workgroup tail kernel
     long fuse_below = 200000;  // levels with fewer cells use the fused (launch-saving) kernels
     DBuf<char> lvdev;          // device array of level descriptors (LevelDev) for the tail kernel

@@ -246,7 +246,7 @@ template <int B, int NS, int NC, int MODE>
 __global__ __launch_bounds__(256) void k_spmv_block(GridDev g, const double *__restrict__ J,
                                                     const double *__restrict__ x, const double *__restrict__ x0,
                                                     double *__restrict__ y) {
-    const long tid = (long)blockIdx.x * blockDim.x + threadIdx.x;
+    const long tid = xcd_tid();
     if (tid >= g.nown) return;
     const long c = g.np + tid, nt = g.ntot;
     const long off[7] = {0, -1, 1, -(long)g.n0, (long)g.n0, -g.np, g.np};
@@ -269,7 +269,7 @@ __global__ __launch_bounds__(256) void k_spmv_block(GridDev g, const double *__r
 
 void spmv_block(tp_ctx *c, const double *J, const double *x, double *y) {
     const GridDev &g = c->g;
-    const dim3 gr = grid_for(g.nown), bl(256);
+    const dim3 gr = xcd_grid(g.nown), bl(256);
     const bool d3 = g.gn2 > 1;
     if (c->b == 3) {
         if (d3) hipLaunchKernelGGL((k_spmv_block<3, 7, 3, 0>), gr, bl, 0, c->stream, g, J, x, x, y);
@@ -283,7 +283,7 @@ void spmv_block(tp_ctx *c, const double *J, const double *x, double *y) {
 
 void resid_block_cols(tp_ctx *c, const double *J, const double *x, const double *y, int ncols, double *r) {
     const GridDev &g = c->g;
-    const dim3 gr = grid_for(g.nown), bl(256);
+    const dim3 gr = xcd_grid(g.nown), bl(256);
     const bool d3 = g.gn2 > 1;
 #define RL(B, NS, NC) hipLaunchKernelGGL((k_spmv_block<B, NS, NC, 1>), gr, bl, 0, c->stream, g, J, y, x, r)
     if (c->b == 3) {
@@ -302,7 +302,7 @@ void resid_block_cols(tp_ctx *c, const double *J, const double *x, const double 
 __global__ __launch_bounds__(256) void k_spmv_scalar(GridDev g, Stencil A, const double *__restrict__ x,
                                                      double *__restrict__ y, double alpha,
                                                      const double *__restrict__ z) {
-    const long tid = (long)blockIdx.x * blockDim.x + threadIdx.x;
+    const long tid = xcd_tid();
     if (tid >= g.nown) return;
     const long c = g.np + tid;
     const long off[7] = {0, -1, 1, -(long)g.n0, (long)g.n0, -g.np, g.np};
@@ -314,7 +314,7 @@ __global__ __launch_bounds__(256) void k_spmv_scalar(GridDev g, Stencil A, const
 
 void spmv_scalar(tp_ctx *c, const GridDev &g, const Stencil &A, const double *x, double *y, double alpha,
                  const double *z) {
-    hipLaunchKernelGGL(k_spmv_scalar, grid_for(g.nown), dim3(256), 0, c->stream, g, A, x, y, alpha, z);
+    hipLaunchKernelGGL(k_spmv_scalar, xcd_grid(g.nown), dim3(256), 0, c->stream, g, A, x, y, alpha, z);
     TP_HIP(hipGetLastError());
 }
 
