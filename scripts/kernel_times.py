@@ -19,5 +19,5 @@ print("its", tot, flush=True)
 print("steps %.3fs" % (time.time() - t), "failed", m.failed_solves)
 e = m.engine
 e.lib.tp_jacobian(e.ctx); e.pc_setup()
-for w, nm in enumerate(["spmv", "ilu_solve", "amg_vcycle", "assembly", "pc_apply"]):
+for w, nm in enumerate(["spmv", "ilu_solve", "amg_vcycle", "assembly", "pc_apply", "pc_setup", "ilu_factor"]):
     print("%-12s %.3f ms" % (nm, e.time_kernel(w, 20)), flush=True)

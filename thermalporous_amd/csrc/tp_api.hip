@@ -636,6 +636,8 @@ int tp_time_kernel(tp_ctx *c, int32_t which, int32_t reps, double *ms_avg) {
                 break;
             case 3: assemble(c, true, c->opt.pc_kind == 1); break;
             case 4: pc_apply(c, c->R.p, c->dx.p); break;
+            case 5: pc_setup(c); break;
+            case 6: ilu_factor(c); break;
             default: throw Error("unknown kernel id");
         }
     };

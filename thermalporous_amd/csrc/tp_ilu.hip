@@ -100,16 +100,39 @@ __global__ __launch_bounds__(64) void k_ilu_factor(IluGeom G, const double *__re
     const int tile = blockIdx.x, lane = threadIdx.x;
     const long nt = G.g.ntot;
     const TileInfo ti = tile_info(G, tile, lane);
+    const int ns = G.nsteps;
     double Dp[B][B];                       // D~^-1 of this lane's previous cell (axis-0 lower neighbour)
 #pragma unroll
     for (int r = 0; r < B; ++r)
 #pragma unroll
         for (int q = 0; q < B; ++q) Dp[r][q] = 0.0;
     const long stride[3] = {1, (long)G.g.n0, G.g.np};
-    for (int s = 0; s < G.nsteps; ++s) {
+    // the Jacobian blocks of a step are gathered one step ahead (their addresses do not depend on the recurrence)
+    struct Blk {
+        double D[B][B], Acm[3][B][B], Amc[3][B][B], Aup[3][B][B];
+        bool ok, has[3], hasu[3];
+    };
+    Blk buf[2];
+    auto load = [&](Blk &k, int s) {
         int l0;
         long c;
-        const bool ok = tile_cell(G, ti, s, l0, c);
+        k.ok = tile_cell(G, ti, s, l0, c);
+        k.has[0] = k.ok && l0 > 0; k.has[1] = k.ok && ti.j > 0; k.has[2] = k.ok && ti.k > 0;
+        k.hasu[0] = k.ok && l0 < ti.tt0 - 1; k.hasu[1] = k.ok && ti.j < ti.tj - 1; k.hasu[2] = k.ok && ti.k < ti.tk - 1;
+#pragma unroll
+        for (int r = 0; r < B; ++r)
+#pragma unroll
+            for (int q = 0; q < B; ++q) {
+                k.D[r][q] = k.ok ? J[((long)(0 * B + r) * B + q) * nt + c] : 0.0;
+#pragma unroll
+                for (int a = 0; a < 3; ++a) {
+                    k.Acm[a][r][q] = k.has[a] ? J[((long)((1 + 2 * a) * B + r) * B + q) * nt + c] : 0.0;
+                    k.Amc[a][r][q] = k.has[a] ? J[((long)((2 + 2 * a) * B + r) * B + q) * nt + c - stride[a]] : 0.0;
+                    k.Aup[a][r][q] = k.hasu[a] ? J[((long)((2 + 2 * a) * B + r) * B + q) * nt + c] : 0.0;
+                }
+            }
+    };
+    auto step = [&](const Blk &k, int s) {
         // D~^-1 of the three lower neighbours (previous step): self, lane-1, lane-t1
         double Dn[3][B][B];
 #pragma unroll
@@ -120,62 +143,39 @@ __global__ __launch_bounds__(64) void k_ilu_factor(IluGeom G, const double *__re
                 Dn[1][r][q] = __shfl_up(Dp[r][q], 1, 64);
                 Dn[2][r][q] = __shfl_up(Dp[r][q], G.t1, 64);
             }
-        const bool has[3] = {ok && l0 > 0, ok && ti.j > 0, ok && ti.k > 0};
         double D[B][B], Di[B][B];
-        double *fch = fwd + ((long)tile * G.nsteps + s) * (L::PF * 128);
-        double *bch = bwd + ((long)tile * G.nsteps + s) * (L::PB * 128);
-        if (ok) {
+        double *fch = fwd + ((long)tile * ns + s) * (L::PF * 128);
+        double *bch = bwd + ((long)tile * ns + s) * (L::PB * 128);
 #pragma unroll
-            for (int r = 0; r < B; ++r)
+        for (int r = 0; r < B; ++r)
 #pragma unroll
-                for (int q = 0; q < B; ++q) D[r][q] = J[((long)(0 * B + r) * B + q) * nt + c];
-        }
+            for (int q = 0; q < B; ++q) D[r][q] = k.D[r][q];
 #pragma unroll
         for (int a = 0; a < 3; ++a) {
-            double Bm[B][B];                   // B_cm = A_cm D~_m^-1
-#pragma unroll
-            for (int r = 0; r < B; ++r)
-#pragma unroll
-                for (int q = 0; q < B; ++q) Bm[r][q] = 0.0;
-            if (has[a]) {
-                const long m = c - stride[a];
-                double Acm[B][B], Amc[B][B];
-#pragma unroll
-                for (int r = 0; r < B; ++r)
-#pragma unroll
-                    for (int q = 0; q < B; ++q) {
-                        Acm[r][q] = J[((long)((1 + 2 * a) * B + r) * B + q) * nt + c];
-                        Amc[r][q] = J[((long)((2 + 2 * a) * B + r) * B + q) * nt + m];
-                    }
-#pragma unroll
-                for (int r = 0; r < B; ++r)
-#pragma unroll
-                    for (int q = 0; q < B; ++q) {
-                        double v = 0.0;
-#pragma unroll
-                        for (int t = 0; t < B; ++t) v += Acm[r][t] * Dn[a][t][q];
-                        Bm[r][q] = v;
-                    }
-#pragma unroll
-                for (int r = 0; r < B; ++r)
-#pragma unroll
-                    for (int q = 0; q < B; ++q) {
-                        double v = 0.0;
-#pragma unroll
-                        for (int t = 0; t < B; ++t) v += Bm[r][t] * Amc[t][q];
-                        D[r][q] -= v;
-                    }
-            }
+            double Bm[B][B];                   // B_cm = A_cm D~_m^-1 (zero when the neighbour is outside the tile)
 #pragma unroll
             for (int r = 0; r < B; ++r)
 #pragma unroll
                 for (int q = 0; q < B; ++q) {
+                    double v = 0.0;
+#pragma unroll
+                    for (int t = 0; t < B; ++t) v += k.Acm[a][r][t] * Dn[a][t][q];
+                    Bm[r][q] = k.has[a] ? v : 0.0;
+                }
+#pragma unroll
+            for (int r = 0; r < B; ++r)
+#pragma unroll
+                for (int q = 0; q < B; ++q) {
+                    double v = 0.0;
+#pragma unroll
+                    for (int t = 0; t < B; ++t) v += Bm[r][t] * k.Amc[a][t][q];
+                    D[r][q] -= v;
                     const int e = (a * B + r) * B + q;
                     fch[(e >> 1) * 128 + lane * 2 + (e & 1)] = Bm[r][q];
                 }
         }
         if (L::NEF & 1) fch[(L::NEF >> 1) * 128 + lane * 2 + 1] = 0.0;    // padding half of the last pair
-        if (ok) {
+        if (k.ok) {
             inv_block<B>(D, Di);
         } else {
 #pragma unroll
@@ -184,33 +184,18 @@ __global__ __launch_bounds__(64) void k_ilu_factor(IluGeom G, const double *__re
                 for (int q = 0; q < B; ++q) Di[r][q] = 0.0;
         }
         // backward-sweep data: C_cm = D~_c^-1 A_cm for the three upper neighbours in the tile, then D~_c^-1
-        const bool hasu[3] = {ok && l0 < ti.tt0 - 1, ok && ti.j < ti.tj - 1, ok && ti.k < ti.tk - 1};
 #pragma unroll
-        for (int a = 0; a < 3; ++a) {
-            double Cm[B][B];
-#pragma unroll
-            for (int r = 0; r < B; ++r)
-#pragma unroll
-                for (int q = 0; q < B; ++q) Cm[r][q] = 0.0;
-            if (hasu[a]) {
-#pragma unroll
-                for (int r = 0; r < B; ++r)
-#pragma unroll
-                    for (int q = 0; q < B; ++q) {
-                        double v = 0.0;
-#pragma unroll
-                        for (int t = 0; t < B; ++t) v += Di[r][t] * J[((long)((2 + 2 * a) * B + t) * B + q) * nt + c];
-                        Cm[r][q] = v;
-                    }
-            }
+        for (int a = 0; a < 3; ++a)
 #pragma unroll
             for (int r = 0; r < B; ++r)
 #pragma unroll
                 for (int q = 0; q < B; ++q) {
+                    double v = 0.0;
+#pragma unroll
+                    for (int t = 0; t < B; ++t) v += Di[r][t] * k.Aup[a][t][q];
                     const int e = (a * B + r) * B + q;
-                    bch[(e >> 1) * 128 + lane * 2 + (e & 1)] = Cm[r][q];
+                    bch[(e >> 1) * 128 + lane * 2 + (e & 1)] = k.hasu[a] ? v : 0.0;
                 }
-        }
 #pragma unroll
         for (int r = 0; r < B; ++r)
 #pragma unroll
@@ -219,6 +204,15 @@ __global__ __launch_bounds__(64) void k_ilu_factor(IluGeom G, const double *__re
                 bch[(e >> 1) * 128 + lane * 2 + (e & 1)] = Di[r][q];
                 Dp[r][q] = Di[r][q];
             }
+    };
+    load(buf[0], 0);
+    for (int s = 0; s < ns; s += 2) {
+        if (s + 1 < ns) load(buf[1], s + 1);
+        step(buf[0], s);
+        if (s + 1 < ns) {
+            if (s + 2 < ns) load(buf[0], s + 2);
+            step(buf[1], s + 1);
+        }
     }
 }
 
