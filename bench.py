@@ -132,6 +132,16 @@ def main():
                                                        (4, "pc_apply_ms"))}
     if rank != 0:
         return
+    # HBM traffic per launch of the same kernel from the PMC passes (rocprofv3 --pmc FETCH_SIZE / WRITE_SIZE in
+    # separate runs, gfx950 correction applied; see profiles/r01_pmc_traffic.json "how"): only quoted when the
+    # committed profile is of this very launch shape
+    traffic = None
+    try:
+        prof = json.load(open(os.path.join(os.path.dirname(os.path.abspath(__file__)), "profiles", "r01_pmc_traffic.json")))
+        if prof["cells"] == ncell_local and eng.b == 3:
+            traffic = prof["kernels"]["tp::k_spmv_block<3, 7, 3, 0>"]["traffic_bytes"]
+    except (OSError, KeyError, ValueError):
+        pass
     out = {
         "metric": "Newton steps/s, SPE10 60x220x85 two-phase (FGMRES its/s in config)",
         "value": nits/el,
@@ -155,7 +165,7 @@ def main():
             "kernels_ms": dict(spmv_ms=ms, **extra),
         },
         "roofline": {"bound": "hbm", "achieved": achieved, "peak": HBM_PEAK_GBS, "unit": "GB/s",
-                     "frac": achieved/HBM_PEAK_GBS, "traffic": None,
+                     "frac": achieved/HBM_PEAK_GBS, "traffic": traffic,
                      "kernel": "k_spmv_block<3,7,3,0>", "bytes_per_cell": bpc, "cells_per_launch": ncell_local,
                      "avg_ms": ms},
     }

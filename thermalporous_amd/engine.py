@@ -133,7 +133,7 @@ class HipEngine:
         self._opt = self._make_options(self.opts)
         self.ctx = C.c_void_p()
         if device is None:
-            device = int(os.environ.get("LOCAL_RANK", "0")) if (self.nranks > 1 and local_group is None) else 0
+            device = int(os.environ.get("TP_LOCAL_DEVICE", os.environ.get("LOCAL_RANK", "0"))) if (self.nranks > 1 and local_group is None) else 0
         self._ck(self.lib.tp_create(C.byref(g), C.byref(prm), C.byref(self._opt), int(device), C.byref(self.ctx)))
         if self.nranks > 1 and local_group is not None:
             # N engines in N threads of this process sharing one GPU (validation of the slab algorithm)

@@ -17,6 +17,12 @@ def world():
     return int(os.environ.get("RANK", "0")), int(os.environ.get("WORLD_SIZE", "1"))
 
 
+def local_device():
+    """GPU index of this rank: LOCAL_RANK, unless TP_LOCAL_DEVICE pins every rank to one card (rehearsing the
+    N-rank path on a one-GPU box)."""
+    return int(os.environ.get("TP_LOCAL_DEVICE", os.environ.get("LOCAL_RANK", "0")))
+
+
 def _dist():
     import torch.distributed as dist
     return dist
@@ -40,7 +46,7 @@ def init(backend=None):
     if backend is None:
         backend = "nccl" if torch.cuda.is_available() else "gloo"
     if backend == "nccl":
-        torch.cuda.set_device(int(os.environ.get("LOCAL_RANK", "0")))
+        torch.cuda.set_device(local_device())
     os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
     dist.init_process_group(backend=backend, rank=rank, world_size=size)
     return rank, size
@@ -50,7 +56,7 @@ def _device():
     import torch
     dist = _dist()
     if dist.get_backend() == "nccl":
-        return torch.device("cuda", int(os.environ.get("LOCAL_RANK", "0")))
+        return torch.device("cuda", local_device())
     return torch.device("cpu")
 
 
