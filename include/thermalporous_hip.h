@@ -78,6 +78,9 @@ typedef struct tp_options {
     int32_t amg_full_levels; /* V(nu,nu) on the first amg_full_levels levels ... */
     int32_t amg_coarse_pre, amg_coarse_post;  /* ... V(coarse_pre, coarse_post) below (coarse_post >= 1) */
     int32_t amg_single;      /* 1: AMG operators/weights stored in fp32 (vectors and arithmetic stay fp64) */
+    int32_t amg_gather_cells;/* multi-GPU: AMG levels with more cells than this stay distributed over the slabs
+                                (halo exchange per sweep); smaller ones are gathered and replicated on every
+                                rank.  < 0: replicate the whole hierarchy.  Ignored on one GPU. */
 } tp_options;
 
 /* Result of one nonlinear solve (SNES iteration number / linear iterations / reason:
@@ -160,6 +163,9 @@ int tp_newton_solve(tp_ctx *ctx, tp_solve_info *info);
  * 3 assembly (residual+Jacobian), 4 full pc_apply, 5 pc_setup, 6 ILU factorisation. */
 int tp_time_kernel(tp_ctx *ctx, int32_t which, int32_t reps, double *ms_avg);
 int tp_amg_info(tp_ctx *ctx, int32_t which, int32_t *nlevels, double *op_complexity);
+/* coarsening axis of every level (internal axis numbering, 2 = slab axis) and how many of the top levels are
+ * distributed over the slabs (0 on one GPU and when the hierarchy is replicated, see amg_gather_cells) */
+int tp_amg_layout(tp_ctx *ctx, int32_t which, int32_t *dist_levels, int32_t *axes, int32_t cap, int32_t *naxes);
 
 #ifdef __cplusplus
 }

@@ -46,6 +46,12 @@ __device__ __forceinline__ void cell_ijk(const GridDev &g, long tid, int &i0, in
     i0 = rem - i1 * g.n0;
 }
 
+// Multi-GPU: along the slab axis (2) the C points are the even GLOBAL planes, so a slab that starts on an odd
+// plane is shifted by one; its F neighbours / C parents across the slab boundary live in the halo planes.
+__device__ __forceinline__ int par_of(const GridDev &gf, int a) { return a == 2 ? (gf.off2 & 1) : 0; }
+__device__ __forceinline__ bool open_lo(const GridDev &g, int a) { return a == 2 && g.nb_lo; }
+__device__ __forceinline__ bool open_hi(const GridDev &g, int a) { return a == 2 && g.nb_hi; }
+
 // ---- set-up kernels --------------------------------------------------------------------------------
 // interpolation weights of every cell w.r.t. axis a (only odd cells are used) + invd = omega/diag
 template <class R>
@@ -66,18 +72,19 @@ __global__ void k_amg_weights(GridDev g, StencilT<R> A, int axis, double omega, 
 
 // coarse operator: one thread per coarse cell
 template <class R>
-__global__ void k_amg_coarsen(GridDev gf, GridDev gc, StencilT<R> A, int axis, const R *wm, const R *wp, R *Ac) {
+__global__ void k_amg_coarsen(GridDev gf, GridDev gc, StencilT<R> A, int axis, const R *wm, const R *wp, R *Ac,
+                              long cstride) {
     const long tid = (long)blockIdx.x * blockDim.x + threadIdx.x;
     if (tid >= gc.nown) return;
     int I[3];
     cell_ijk(gc, tid, I[0], I[1], I[2]);
     const long cc = gc.np + tid;
     int F[3] = {I[0], I[1], I[2]};
-    F[axis] = 2 * I[axis];
+    F[axis] = 2 * I[axis] + par_of(gf, axis);
     const int nfa = axis == 0 ? gf.n0 : (axis == 1 ? gf.n1 : gf.n2);
     const long stride = axis == 0 ? 1 : (axis == 1 ? gf.n0 : gf.np);
     const long f = gf.np + (long)F[0] + (long)gf.n0 * F[1] + gf.np * F[2];
-    const bool hm = F[axis] - 1 >= 0, hp = F[axis] + 1 < nfa;
+    const bool hm = F[axis] - 1 >= 0 || open_lo(gf, axis), hp = F[axis] + 1 < nfa || open_hi(gf, axis);
     const long gm = f - stride, gp = f + stride;
     const double Pm = hm ? wp[gm] : 0.0;     // P[g-, I] = w+(g-)
     const double Pp = hp ? wm[gp] : 0.0;     // P[g+, I] = w-(g+)
@@ -100,7 +107,7 @@ __global__ void k_amg_coarsen(GridDev gf, GridDev gc, StencilT<R> A, int axis, c
     }
     out[0] = -offsum + rho_f + Pm * rho_m + Pp * rho_p;
 #pragma unroll
-    for (int s = 0; s < 7; ++s) Ac[(long)s * gc.ntot + cc] = (R)out[s];
+    for (int s = 0; s < 7; ++s) Ac[(long)s * cstride + cc] = (R)out[s];
 }
 
 // coarsest grid: dense inverse by Gauss-Jordan in one workgroup (diagonally dominant: no pivoting)
@@ -242,8 +249,8 @@ __device__ __forceinline__ double resid_restrict_cell(const LevelDevT<R> &Lf, co
     cell_ijk(gc, tidc, I[0], I[1], I[2]);
     const int a = Lf.axis;
     int F[3] = {I[0], I[1], I[2]};
-    F[a] = 2 * I[a];
     const GridDev &gf = Lf.g;
+    F[a] = 2 * I[a] + par_of(gf, a);       // (slab-axis levels of a multi-GPU hierarchy use the unfused path)
     const int nfa = a == 0 ? gf.n0 : (a == 1 ? gf.n1 : gf.n2);
     const long stride = a == 0 ? 1 : (a == 1 ? gf.n0 : gf.np);
     const long f = gf.np + (long)F[0] + (long)gf.n0 * F[1] + gf.np * F[2];
@@ -261,32 +268,35 @@ __device__ __forceinline__ double restrict_cell(const LevelDevT<R> &Lf, const Gr
     cell_ijk(gc, tidc, I[0], I[1], I[2]);
     const int a = Lf.axis;
     int F[3] = {I[0], I[1], I[2]};
-    F[a] = 2 * I[a];
     const GridDev &gf = Lf.g;
+    F[a] = 2 * I[a] + par_of(gf, a);
     const int nfa = a == 0 ? gf.n0 : (a == 1 ? gf.n1 : gf.n2);
     const long stride = a == 0 ? 1 : (a == 1 ? gf.n0 : gf.np);
     const long f = gf.np + (long)F[0] + (long)gf.n0 * F[1] + gf.np * F[2];
     double v = r[f];
-    if (F[a] - 1 >= 0) v += Lf.wp[f - stride] * r[f - stride];
-    if (F[a] + 1 < nfa) v += Lf.wm[f + stride] * r[f + stride];
+    if (F[a] - 1 >= 0 || open_lo(gf, a)) v += Lf.wp[f - stride] * r[f - stride];
+    if (F[a] + 1 < nfa || open_hi(gf, a)) v += Lf.wm[f + stride] * r[f + stride];
     return v;
 }
 
-// (P ec) at fine cell (F0,F1,F2)
+// (P ec) at fine cell (F0,F1,F2); along the slab axis F2 may be a halo plane (-1 or n2) and the parents may sit in
+// the coarse halo planes
 template <class R>
 __device__ __forceinline__ double prolong_at(const LevelDevT<R> &Lf, const GridDev &gc, const double *__restrict__ ec,
                                              int F0, int F1, int F2) {
     const int a = Lf.axis;
     const int Fa = a == 0 ? F0 : (a == 1 ? F1 : F2);
+    const int p = par_of(Lf.g, a);
+    const int Ia = (Fa - p) >> 1;                   // floor: the C point itself, or the left parent of an F point
     int I0 = F0, I1 = F1, I2 = F2;
-    if (a == 0) I0 = F0 >> 1; else if (a == 1) I1 = F1 >> 1; else I2 = F2 >> 1;
+    if (a == 0) I0 = Ia; else if (a == 1) I1 = Ia; else I2 = Ia;
     const long ci = gc.np + (long)I0 + (long)gc.n0 * I1 + gc.np * I2;
-    if ((Fa & 1) == 0) return ec[ci];
+    if (((Fa + p) & 1) == 0) return ec[ci];
     const long c = Lf.g.np + (long)F0 + (long)Lf.g.n0 * F1 + Lf.g.np * F2;
     const long cs = a == 0 ? 1 : (a == 1 ? gc.n0 : gc.np);
     const int nca = a == 0 ? gc.n0 : (a == 1 ? gc.n1 : gc.n2);
     double e = Lf.wm[c] * ec[ci];
-    if ((Fa >> 1) + 1 < nca) e += Lf.wp[c] * ec[ci + cs];
+    if (Ia + 1 < nca || open_hi(gc, a)) e += Lf.wp[c] * ec[ci + cs];
     return e;
 }
 
@@ -308,8 +318,8 @@ __device__ __forceinline__ double prolong_jacobi_cell(const LevelDevT<R> &Lf, co
     if (i0 < g.n0 - 1) s += Lf.op.slot(2)[c] * (xv(c + 1) + prolong_at(Lf, gc, ec, i0 + 1, i1, i2));
     if (i1 > 0)        s += Lf.op.slot(3)[c] * (xv(c - g.n0) + prolong_at(Lf, gc, ec, i0, i1 - 1, i2));
     if (i1 < g.n1 - 1) s += Lf.op.slot(4)[c] * (xv(c + g.n0) + prolong_at(Lf, gc, ec, i0, i1 + 1, i2));
-    if (i2 > 0)        s += Lf.op.slot(5)[c] * (xv(c - g.np) + prolong_at(Lf, gc, ec, i0, i1, i2 - 1));
-    if (i2 < g.n2 - 1) s += Lf.op.slot(6)[c] * (xv(c + g.np) + prolong_at(Lf, gc, ec, i0, i1, i2 + 1));
+    if (i2 > 0 || g.nb_lo)        s += Lf.op.slot(5)[c] * (xv(c - g.np) + prolong_at(Lf, gc, ec, i0, i1, i2 - 1));
+    if (i2 < g.n2 - 1 || g.nb_hi) s += Lf.op.slot(6)[c] * (xv(c + g.np) + prolong_at(Lf, gc, ec, i0, i1, i2 + 1));
     return xc + Lf.invd[c] * (b[c] - s);
 }
 
@@ -475,17 +485,39 @@ static LevelDevT<R> dev_of(const AmgLevel *L, int level, const tp_options &o) {
     return d;
 }
 
+// g0: the grid the hierarchy coarsens -- the slab itself on one GPU, the GLOBAL grid on several.  There the top
+// levels (more than amg_gather_cells cells, at least two planes on every rank) stay distributed over the slabs
+// and the rest of the hierarchy is built on the gathered global grid, replicated on every rank; a problem
+// smaller than amg_gather_cells is replicated from the top (dist_levels = 0: its V-cycle is launch-latency
+// bound and would only get slower with a halo exchange between sweeps).
 void amg_build(tp_ctx *c, Amg *&amg, const GridDev &g0, const double strength[3]) {
     delete amg;
     amg = new Amg();
     amg->single = c->opt.amg_single != 0;
     const int n[3] = {g0.n0, g0.n1, g0.n2};
     amg->sched = schedule(n, strength, std::max(1, c->opt.amg_min_cells));
+    const int nranks = c->dist ? c->grid.nranks : 1, me = c->dist ? c->grid.rank : 0;
+    std::vector<std::pair<int, int>> cur(nranks);          // owned global planes of every rank at the current level
+    for (int r = 0; r < nranks; ++r) {
+        if (c->dist) slab_of(c, r, cur[r].first, cur[r].second);
+        else cur[r] = {0, n[2]};
+    }
+    const long gather_cells = c->opt.amg_gather_cells;
+    bool still = c->dist && gather_cells >= 0;
     int m[3] = {n[0], n[1], n[2]};
     for (size_t l = 0; l <= amg->sched.size(); ++l) {
         AmgLevel *L = new AmgLevel();
-        // every level is a box with dead halo planes (multi-GPU: the hierarchy lives on the gathered global grid)
-        L->g = make_grid(m[0], m[1], m[2], m[2], 0);
+        if (still) {
+            int minp = 1 << 30;
+            for (auto &q : cur) minp = std::min(minp, q.second - q.first);
+            still = (long)m[0] * m[1] * m[2] > gather_cells && minp >= 2 && l < amg->sched.size();
+            if (still) amg->dist_levels = (int)l + 1;
+        }
+        amg->ranges.push_back(cur);
+        // a distributed level is this rank's slab of the level (live halo planes towards the neighbours);
+        // every other level is the whole box with dead halo planes
+        L->g = still ? make_grid(m[0], m[1], cur[me].second - cur[me].first, m[2], cur[me].first)
+                     : make_grid(m[0], m[1], m[2], m[2], 0);
         const size_t nt = (size_t)L->g.ntot;
         // operator/weight buffers are sized for doubles and hold floats when amg_single (slot stride in elements)
         if (l > 0 || amg->single) {
@@ -499,6 +531,8 @@ void amg_build(tp_ctx *c, Amg *&amg, const GridDev &g0, const double strength[3]
             L->axis = amg->sched[l];
             L->wm.alloc(nt); L->wp.alloc(nt);
             m[L->axis] = (m[L->axis] + 1) / 2;
+            if (L->axis == 2)
+                for (auto &q : cur) q = {(q.first + 1) / 2, (q.second + 1) / 2};     // even global planes survive
         }
         amg->lv.push_back(L);
     }
@@ -509,9 +543,27 @@ void amg_build(tp_ctx *c, Amg *&amg, const GridDev &g0, const double strength[3]
     const long tail_cells = getenv("TP_AMG_TAIL_CELLS") ? atol(getenv("TP_AMG_TAIL_CELLS")) : 1024;
     amg->fuse_below = getenv("TP_AMG_FUSE_BELOW") ? atol(getenv("TP_AMG_FUSE_BELOW")) : 200000;
     amg->tail_level = (int)amg->lv.size() - 1;
-    for (size_t l = 0; l < amg->lv.size(); ++l)
+    for (size_t l = (size_t)amg->dist_levels; l < amg->lv.size(); ++l)
         if (amg->lv[l]->g.nown <= tail_cells) { amg->tail_level = (int)l; break; }
     amg->lvdev.alloc(amg->lv.size() * sizeof(LevelDevT<double>));
+}
+
+// level l+1 as its parent level l sees it.  Below the last distributed level that is this rank's planes of the
+// global (replicated) arrays -- pointer arithmetic, no copy: plane 0 of the view is the lower halo.
+struct CoarseView {
+    GridDev g;
+    long off;          // element offset of the view inside the level's arrays
+    long slot_stride;  // operator slot stride of the level's arrays
+};
+static CoarseView coarse_view(const tp_ctx *c, const Amg *amg, int l) {
+    const AmgLevel *Lc = amg->lv[l + 1];
+    CoarseView v;
+    v.slot_stride = Lc->g.ntot;
+    if (l + 1 < amg->dist_levels || l >= amg->dist_levels) { v.g = Lc->g; v.off = 0; return v; }
+    const auto &q = amg->ranges[l + 1][c->grid.rank];
+    v.g = make_grid(Lc->g.n0, Lc->g.n1, q.second - q.first, Lc->g.n2, q.first);
+    v.off = Lc->g.np * q.first;
+    return v;
 }
 
 // level-0 operator: double stencil view of the Jacobian -> storage type R
@@ -527,6 +579,7 @@ __global__ void k_amg_import(GridDev g, Stencil A0, R *out) {
 template <class R>
 static void setup_impl(tp_ctx *c, Amg *amg, const Stencil &A0) {
     AmgLevel *L0 = amg->lv[0];
+    const int lg = amg->dist_levels;
     if (sizeof(R) == sizeof(double)) {
         L0->op = A0;                     // zero-copy view of the Jacobian planes
     } else {
@@ -539,10 +592,21 @@ static void setup_impl(tp_ctx *c, Amg *amg, const Stencil &A0) {
         const StencilT<R> op{(R *)L->op.base, L->op.slot_stride};
         hipLaunchKernelGGL(k_amg_weights<R>, grid_for(L->g.nown), dim3(256), 0, c->stream, L->g, op, L->axis,
                            c->opt.amg_omega, (R *)L->wm.p, (R *)L->wp.p, (R *)L->invd.p);
+        if ((int)l < lg) {
+            // distributed level: the cycle reads inverse diagonals and weights of the neighbours' boundary planes,
+            // coarsening along the slab axis also their operator rows
+            halo_exchange_raw(c, L->g, L->invd.p, 1, 0, sizeof(R));
+            halo_exchange_raw(c, L->g, L->wm.p, 1, 0, sizeof(R));
+            halo_exchange_raw(c, L->g, L->wp.p, 1, 0, sizeof(R));
+            if (L->axis == 2) halo_exchange_raw(c, L->g, L->op.base, 7, (size_t)L->op.slot_stride * sizeof(R), sizeof(R));
+        }
         if (L->axis >= 0) {
             AmgLevel *Lc = amg->lv[l + 1];
-            hipLaunchKernelGGL(k_amg_coarsen<R>, grid_for(Lc->g.nown), dim3(256), 0, c->stream, L->g, Lc->g, op, L->axis,
-                               (const R *)L->wm.p, (const R *)L->wp.p, (R *)Lc->A.p);
+            const CoarseView cv = coarse_view(c, amg, (int)l);
+            hipLaunchKernelGGL(k_amg_coarsen<R>, grid_for(cv.g.nown), dim3(256), 0, c->stream, L->g, cv.g, op, L->axis,
+                               (const R *)L->wm.p, (const R *)L->wp.p, (R *)Lc->A.p + cv.off, cv.slot_stride);
+            if ((int)l + 1 == lg)        // first replicated level: everybody gets everybody's rows
+                gather_ranges(c, Lc->A.p, Lc->g.np, amg->ranges[lg], 7, (size_t)Lc->g.ntot * sizeof(R), sizeof(R));
         }
     }
     AmgLevel *Lc = amg->lv.back();
@@ -567,37 +631,52 @@ void amg_setup(tp_ctx *c, Amg *amg, const Stencil &A0) {
     else setup_impl<double>(c, amg, A0);
 }
 
+// Multi-GPU, levels [0, lg): the same kernels on this rank's slab of the level, with a halo exchange in front of
+// every kernel that reads a neighbour's value across the slab boundary.  Levels >= lg: the gathered global
+// grid, every rank computing the same thing.  (b's halo planes are overwritten by the exchange.)
 template <class R>
 static void vcycle_impl(tp_ctx *c, Amg *amg, const double *b, double *x) {
-    const int nlev = (int)amg->lv.size(), lt = amg->tail_level;
+    const int nlev = (int)amg->lv.size(), lt = amg->tail_level, lg = amg->dist_levels;
     const dim3 bl(256);
     std::vector<double *> xs(nlev, nullptr);       // pre-smoothed iterate of each big level (null: none)
+    auto hx = [&](int l, const double *v) {        // halo exchange of a level-l vector (no-op below lg)
+        if (l < lg) halo_exchange(c, amg->lv[l]->g, const_cast<double *>(v), 1, 0);
+    };
     // down-sweep over the big levels
     for (int l = 0; l < lt; ++l) {
         AmgLevel *L = amg->lv[l];
         AmgLevel *Lc = amg->lv[l + 1];
         const LevelDevT<R> Ld = dev_of<R>(L, l, c->opt);
+        const CoarseView cv = coarse_view(c, amg, l);
         const double *bl_ = (l == 0) ? b : L->b.p;
+        double *bc = Lc->b.p + cv.off;
         const dim3 gr = xcd_grid(L->g.nown);
+        const bool slab_axis = l < lg && L->axis == 2;      // the transfer itself crosses the slab boundary
         if (Ld.pre == 0) {                          // V(0,post): residual = b
-            hipLaunchKernelGGL(k_amg_restrict<R>, xcd_grid(Lc->g.nown), bl, 0, c->stream, Ld, Lc->g, bl_, Lc->b.p);
-            continue;
-        }
-        double *cur = L->x.p, *oth = L->x2.p;
-        hipLaunchKernelGGL(k_amg_pre<R>, gr, bl, 0, c->stream, Ld, bl_, Ld.pre >= 2 ? 1 : 0, cur);
-        for (int k = 2; k < Ld.pre; ++k) {
-            hipLaunchKernelGGL(k_amg_jacobi<R>, gr, bl, 0, c->stream, Ld, bl_, (const double *)cur, oth);
-            std::swap(cur, oth);
-        }
-        xs[l] = cur;
-        if (L->g.nown >= amg->fuse_below) {
-            hipLaunchKernelGGL(k_amg_resid<R>, gr, bl, 0, c->stream, Ld, bl_, (const double *)cur, oth);
-            hipLaunchKernelGGL(k_amg_restrict<R>, xcd_grid(Lc->g.nown), bl, 0, c->stream, Ld, Lc->g, (const double *)oth,
-                               Lc->b.p);
+            if (slab_axis) hx(l, bl_);
+            hipLaunchKernelGGL(k_amg_restrict<R>, xcd_grid(cv.g.nown), bl, 0, c->stream, Ld, cv.g, bl_, bc);
         } else {
-            hipLaunchKernelGGL(k_amg_resid_restrict<R>, xcd_grid(Lc->g.nown), bl, 0, c->stream, Ld, Lc->g, bl_,
-                               (const double *)cur, Lc->b.p);
+            double *cur = L->x.p, *oth = L->x2.p;
+            if (Ld.pre >= 2) hx(l, bl_);            // the fused double sweep reads invd*b of the neighbours
+            hipLaunchKernelGGL(k_amg_pre<R>, gr, bl, 0, c->stream, Ld, bl_, Ld.pre >= 2 ? 1 : 0, cur);
+            for (int k = 2; k < Ld.pre; ++k) {
+                hx(l, cur);
+                hipLaunchKernelGGL(k_amg_jacobi<R>, gr, bl, 0, c->stream, Ld, bl_, (const double *)cur, oth);
+                std::swap(cur, oth);
+            }
+            xs[l] = cur;
+            hx(l, cur);
+            if (slab_axis || L->g.nown >= amg->fuse_below) {
+                hipLaunchKernelGGL(k_amg_resid<R>, gr, bl, 0, c->stream, Ld, bl_, (const double *)cur, oth);
+                if (slab_axis) hx(l, oth);
+                hipLaunchKernelGGL(k_amg_restrict<R>, xcd_grid(cv.g.nown), bl, 0, c->stream, Ld, cv.g, (const double *)oth, bc);
+            } else {
+                hipLaunchKernelGGL(k_amg_resid_restrict<R>, xcd_grid(cv.g.nown), bl, 0, c->stream, Ld, cv.g, bl_,
+                                   (const double *)cur, bc);
+            }
         }
+        if (l + 1 == lg)        // restricted residual of every slab -> the replicated levels' right-hand side
+            gather_ranges(c, Lc->b.p, Lc->g.np, amg->ranges[lg], 1, 0, sizeof(double));
     }
     // the tail: every level from lt down to the coarsest and back, one launch
     {
@@ -613,21 +692,25 @@ static void vcycle_impl(tp_ctx *c, Amg *amg, const double *b, double *x) {
         AmgLevel *L = amg->lv[l];
         AmgLevel *Lc = amg->lv[l + 1];
         const LevelDevT<R> Ld = dev_of<R>(L, l, c->opt);
+        const CoarseView cv = coarse_view(c, amg, l);
         const double *bl_ = (l == 0) ? b : L->b.p;
         double *out = (l == 0) ? x : L->e.p;
+        const double *ec = Lc->e.p + cv.off;
         const dim3 gr = xcd_grid(L->g.nown);
-        double *src = xs[l];
+        double *src = xs[l];                        // its halo is still the one exchanged before the residual
         double *dst = (Ld.post == 1) ? out : (src == L->x.p ? L->x2.p : L->x.p);
+        hx(l + 1, Lc->e.p);                         // distributed coarse level: parents across the boundary
         if (src && L->g.nown >= amg->fuse_below) {
-            hipLaunchKernelGGL(k_amg_prolong_add<R>, gr, bl, 0, c->stream, Ld, Lc->g, (const double *)Lc->e.p, src);
+            hipLaunchKernelGGL(k_amg_prolong_add<R>, gr, bl, 0, c->stream, Ld, cv.g, ec, src);
+            hx(l, src);
             hipLaunchKernelGGL(k_amg_jacobi<R>, gr, bl, 0, c->stream, Ld, bl_, (const double *)src, dst);
         } else {
-            hipLaunchKernelGGL(k_amg_prolong_jacobi<R>, gr, bl, 0, c->stream, Ld, Lc->g, bl_, (const double *)src,
-                               (const double *)Lc->e.p, dst);
+            hipLaunchKernelGGL(k_amg_prolong_jacobi<R>, gr, bl, 0, c->stream, Ld, cv.g, bl_, (const double *)src, ec, dst);
         }
         for (int k = 1; k < Ld.post; ++k) {
             src = dst;
             dst = (k == Ld.post - 1) ? out : (src == L->x.p ? L->x2.p : L->x.p);
+            hx(l, src);
             hipLaunchKernelGGL(k_amg_jacobi<R>, gr, bl, 0, c->stream, Ld, bl_, (const double *)src, dst);
         }
     }

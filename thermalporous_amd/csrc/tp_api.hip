@@ -5,6 +5,7 @@
 #include <cmath>
 #include <algorithm>
 #include <map>
+#include <utility>
 #include <mutex>
 #include <condition_variable>
 
@@ -51,43 +52,83 @@ static void lg_done(tp_ctx *c) {
 
 // One 1-cell halo plane per side along axis 2; each plane of each field is contiguous, so the
 // exchange is 2*nf send/recv pairs in one RCCL group on the compute stream (<= 2 neighbours, one
-// xGMI link each).
-void halo_exchange(tp_ctx *c, const GridDev &g, double *x, int nf, long fstride) {
+// xGMI link each).  Element size 8 (vectors, fp64 operators) or 4 (fp32 AMG operators); `g` is the
+// grid of the array being exchanged (the slab itself, or one of its distributed AMG levels).
+struct HaloPub { const char *p; size_t fstride; int n2; };
+
+void halo_exchange_raw(tp_ctx *c, const GridDev &g, void *x_, int nf, size_t fstride, size_t elem) {
     if (!c->dist) return;
+    TP_REQUIRE(g.n2 >= 1, "halo exchange of an empty slab");
+    char *x = (char *)x_;
     const int lo = c->grid.rank - 1, hi = c->grid.rank + 1;
+    const size_t pb = (size_t)g.np * elem;       // bytes per plane
     if (c->lgroup) {
-        lg_publish(c, x);
+        HaloPub mine{x, fstride, g.n2};
+        lg_publish(c, &mine);
         for (int f = 0; f < nf; ++f) {
-            double *p = x + (long)f * fstride;
+            char *p = x + (size_t)f * fstride;
             if (g.nb_lo) {       // neighbour's last owned plane -> my lower halo
-                int nlo, nhi;
-                slab_of(c, lo, nlo, nhi);
-                const double *q = (const double *)c->lgroup->ptr[lo] + (long)f * (g.np * (nhi - nlo + 2));
-                TP_HIP(hipMemcpyAsync(p, q + g.np * (nhi - nlo), sizeof(double) * g.np, hipMemcpyDeviceToDevice, c->stream));
+                const HaloPub *q = (const HaloPub *)c->lgroup->ptr[lo];
+                TP_HIP(hipMemcpyAsync(p, q->p + (size_t)f * q->fstride + pb * q->n2, pb, hipMemcpyDeviceToDevice, c->stream));
             }
             if (g.nb_hi) {       // neighbour's first owned plane -> my upper halo
-                int nlo, nhi;
-                slab_of(c, hi, nlo, nhi);
-                const double *q = (const double *)c->lgroup->ptr[hi] + (long)f * (g.np * (nhi - nlo + 2));
-                TP_HIP(hipMemcpyAsync(p + g.np * (g.n2 + 1), q + g.np, sizeof(double) * g.np, hipMemcpyDeviceToDevice, c->stream));
+                const HaloPub *q = (const HaloPub *)c->lgroup->ptr[hi];
+                TP_HIP(hipMemcpyAsync(p + pb * (g.n2 + 1), q->p + (size_t)f * q->fstride + pb, pb, hipMemcpyDeviceToDevice, c->stream));
             }
         }
         lg_done(c);
         return;
     }
     ncclComm_t comm = (ncclComm_t)c->comm;
+    const ncclDataType_t dt = elem == 8 ? ncclDouble : ncclFloat;
+    TP_REQUIRE(elem == 8 || elem == 4, "halo element size");
     TP_NCCL(ncclGroupStart());
     for (int f = 0; f < nf; ++f) {
-        double *p = x + (long)f * fstride;
+        char *p = x + (size_t)f * fstride;
         if (g.nb_lo) {
-            TP_NCCL(ncclSend(p + g.np, g.np, ncclDouble, lo, comm, c->stream));                    // first owned plane
-            TP_NCCL(ncclRecv(p, g.np, ncclDouble, lo, comm, c->stream));                           // lower halo
+            TP_NCCL(ncclSend(p + pb, g.np, dt, lo, comm, c->stream));                      // first owned plane
+            TP_NCCL(ncclRecv(p, g.np, dt, lo, comm, c->stream));                           // lower halo
         }
         if (g.nb_hi) {
-            TP_NCCL(ncclSend(p + g.np * g.n2, g.np, ncclDouble, hi, comm, c->stream));             // last owned plane
-            TP_NCCL(ncclRecv(p + g.np * (g.n2 + 1), g.np, ncclDouble, hi, comm, c->stream));       // upper halo
+            TP_NCCL(ncclSend(p + pb * g.n2, g.np, dt, hi, comm, c->stream));               // last owned plane
+            TP_NCCL(ncclRecv(p + pb * (g.n2 + 1), g.np, dt, hi, comm, c->stream));         // upper halo
         }
     }
+    TP_NCCL(ncclGroupEnd());
+}
+
+void halo_exchange(tp_ctx *c, const GridDev &g, double *x, int nf, long fstride) {
+    halo_exchange_raw(c, g, x, nf, (size_t)fstride * sizeof(double), sizeof(double));
+}
+
+// In-place all-gather on a global-grid array every rank holds: rank r owns global planes
+// [ranges[r].first, ranges[r].second) of each of the nslots planes-sets and broadcasts them to everybody.
+void gather_ranges(tp_ctx *c, void *global_, long np, const std::vector<std::pair<int, int>> &ranges, int nslots,
+                   size_t slot_stride, size_t elem) {
+    TP_REQUIRE(c->dist, "gather_ranges without a communicator");
+    char *global = (char *)global_;
+    const size_t pb = (size_t)np * elem;
+    if (c->lgroup) {
+        lg_publish(c, global);
+        for (int r = 0; r < c->grid.nranks; ++r) {
+            if (r == c->grid.rank) continue;
+            const char *src = (const char *)c->lgroup->ptr[r];
+            const size_t off = pb * (ranges[r].first + 1), len = pb * (ranges[r].second - ranges[r].first);
+            for (int s = 0; s < nslots; ++s)
+                TP_HIP(hipMemcpyAsync(global + s * slot_stride + off, src + s * slot_stride + off, len,
+                                      hipMemcpyDeviceToDevice, c->stream));
+        }
+        lg_done(c);
+        return;
+    }
+    ncclComm_t comm = (ncclComm_t)c->comm;
+    const ncclDataType_t dt = elem == 8 ? ncclDouble : ncclFloat;
+    TP_NCCL(ncclGroupStart());
+    for (int s = 0; s < nslots; ++s)
+        for (int r = 0; r < c->grid.nranks; ++r) {
+            char *buf = global + s * slot_stride + pb * (ranges[r].first + 1);
+            TP_NCCL(ncclBroadcast(buf, buf, (size_t)np * (ranges[r].second - ranges[r].first), dt, r, comm, c->stream));
+        }
     TP_NCCL(ncclGroupEnd());
 }
 
@@ -256,7 +297,7 @@ int tp_set_options(tp_ctx *c, const tp_options *opt) {
     TP_REQUIRE(c && opt, "null argument");
     const bool tile_changed = opt->ilu_t1 != c->opt.ilu_t1 || opt->ilu_t2 != c->opt.ilu_t2 || opt->ilu_t0 != c->opt.ilu_t0;
     const bool amg_changed = opt->amg_min_cells != c->opt.amg_min_cells || opt->pc_kind != c->opt.pc_kind ||
-                             opt->amg_single != c->opt.amg_single;
+                             opt->amg_single != c->opt.amg_single || opt->amg_gather_cells != c->opt.amg_gather_cells;
     c->opt = *opt;
     if (tile_changed) c->ilu.slots = 0;
     if (amg_changed) { delete c->amg_p; c->amg_p = nullptr; delete c->amg_T; c->amg_T = nullptr; }
@@ -581,7 +622,7 @@ int tp_amg_vcycle(tp_ctx *c, int32_t which, int32_t field_b, int32_t b, int32_t 
     TP_REQUIRE(c->pc_ready, "AMG not set up");
     Amg *amg = which == 0 ? c->amg_p : c->amg_T;
     TP_REQUIRE(amg, "this AMG hierarchy does not exist for the selected preconditioner");
-    TP_REQUIRE(!c->dist, "tp_amg_vcycle works on slab vectors: single-slab contexts only");
+    TP_REQUIRE(!c->dist || amg->dist_levels > 0, "tp_amg_vcycle works on slab vectors: not available when the hierarchy is replicated on the gathered global grid");
     TP_REQUIRE(field_b >= 0 && field_b < c->b && field_x >= 0 && field_x < c->b, "bad field index");
     TP_REQUIRE(!(b == x && field_b == field_x), "b and x must differ");
     amg_vcycle(c, amg, vec_of(c, b).p + (long)field_b * c->g.ntot, vec_of(c, x).p + (long)field_x * c->g.ntot);
@@ -591,7 +632,7 @@ int tp_amg_vcycle(tp_ctx *c, int32_t which, int32_t field_b, int32_t b, int32_t 
 int tp_schur_apply(tp_ctx *c, int32_t x, int32_t y) {
     TP_API_BEGIN
     TP_REQUIRE(c->pc_ready && c->amg_T, "S~ AMG not set up (pc_cptr only)");
-    TP_REQUIRE(!c->dist, "tp_schur_apply works on slab vectors: single-slab contexts only");
+    TP_REQUIRE(!c->dist || c->amg_T->dist_levels > 0, "tp_schur_apply works on slab vectors: not available when the hierarchy is replicated on the gathered global grid");
     TP_REQUIRE(x != y, "x and y must differ");
     amg_vcycle(c, c->amg_T, vec_of(c, x).p + c->g.ntot, vec_of(c, y).p + c->g.ntot);
     TP_API_END
@@ -631,7 +672,7 @@ int tp_time_kernel(tp_ctx *c, int32_t which, int32_t reps, double *ms_avg) {
             case 0: spmv_block(c, c->J.p, c->R.p, c->w2.p); break;
             case 1: ilu_solve(c, c->R.p, c->w2.p, nullptr); break;
             case 2:
-                if (c->dist) amg_vcycle(c, c->amg_p, c->gvec.p, c->gvec.p + 2 * c->gfull.ntot);   // global-grid buffers
+                if (c->dist && c->amg_p->dist_levels == 0) amg_vcycle(c, c->amg_p, c->gvec.p, c->gvec.p + 2 * c->gfull.ntot);   // global-grid buffers
                 else amg_vcycle(c, c->amg_p, c->R.p, c->w2.p);
                 break;
             case 3: assemble(c, true, c->opt.pc_kind == 1); break;
@@ -657,9 +698,24 @@ int tp_amg_info(tp_ctx *c, int32_t which, int32_t *nlevels, double *op_complexit
     Amg *amg = which == 0 ? c->amg_p : c->amg_T;
     TP_REQUIRE(amg, "AMG hierarchy not built");
     if (nlevels) *nlevels = (int)amg->lv.size();
-    double s = 0.0;
-    for (auto *l : amg->lv) s += (double)l->g.nown;
-    if (op_complexity) *op_complexity = s / (double)amg->lv[0]->g.nown;
+    double s = 0.0, s0 = 0.0;       // global cells per level (a distributed level holds this rank's slab only)
+    for (size_t l = 0; l < amg->lv.size(); ++l) {
+        const GridDev &g = amg->lv[l]->g;
+        const double cells = (double)g.np * g.gn2;
+        s += cells;
+        if (l == 0) s0 = cells;
+    }
+    if (op_complexity) *op_complexity = s / s0;
+    TP_API_END
+}
+
+int tp_amg_layout(tp_ctx *c, int32_t which, int32_t *dist_levels, int32_t *axes, int32_t cap, int32_t *naxes) {
+    TP_API_BEGIN
+    Amg *amg = which == 0 ? c->amg_p : c->amg_T;
+    TP_REQUIRE(amg, "AMG hierarchy not built");
+    if (dist_levels) *dist_levels = amg->dist_levels;
+    if (naxes) *naxes = (int)amg->sched.size();
+    for (int i = 0; axes && i < cap && i < (int)amg->sched.size(); ++i) axes[i] = amg->sched[i];
     TP_API_END
 }
 

@@ -123,6 +123,10 @@ struct Amg {
     bool single = false;       // operators / weights / inverse diagonals stored in fp32
     int tail_level = 0;        // first level handled by the single-workgroup tail kernel
     long fuse_below = 200000;  // levels with fewer cells use the fused (launch-saving) kernels
+    // multi-GPU: levels [0, dist_levels) live on this rank's slab (halo exchanges between sweeps), the levels
+    // below on the gathered global grid, replicated on every rank.  0 = the whole hierarchy is replicated.
+    int dist_levels = 0;
+    std::vector<std::vector<std::pair<int, int>>> ranges;   // [level][rank] -> owned global planes along axis 2
     DBuf<char> lvdev;          // device array of level descriptors (LevelDev) for the tail kernel
     std::vector<char> lvhost;
     std::vector<int> sched;
@@ -224,6 +228,9 @@ void amg_setup(tp_ctx *c, Amg *amg, const Stencil &A0);
 void amg_vcycle(tp_ctx *c, Amg *amg, const double *b, double *x);
 // comm
 void halo_exchange(tp_ctx *c, const GridDev &g, double *x, int nf, long fstride);
+void halo_exchange_raw(tp_ctx *c, const GridDev &g, void *x, int nf, size_t fstride_bytes, size_t elem_bytes);
+void gather_ranges(tp_ctx *c, void *global, long np, const std::vector<std::pair<int, int>> &ranges, int nslots,
+                   size_t slot_stride_bytes, size_t elem_bytes);
 void allreduce_sum(tp_ctx *c, double *dev, int n);
 void slab_of(const tp_ctx *c, int rank, int &lo, int &hi);
 // gather `nplanes` slab-distributed cell planes into arrays on the global grid (every rank gets all slabs)

@@ -56,9 +56,10 @@ void pc_setup(tp_ctx *c) {
     const bool cptr = c->opt.pc_kind == 1;
     // stage 1: decoupling + AMG hierarchies (CPRStage1PC.update / CPTRStage1PC.update)
     decouple(c);
-    // single GPU: the AMG works on the slab (= whole grid).  Multi-GPU: stage 1 is NOT decomposed -- every
-    // rank gathers the scalar stage-1 operators and runs the V-cycles on the global grid, so that the
-    // preconditioner (and the iteration counts) are those of the single-GPU run; only stage 2 is bjacobi.
+    // single GPU: the AMG works on the slab (= whole grid).  Multi-GPU: the hierarchy is that of the GLOBAL grid,
+    // so the preconditioner (and the iteration counts) are those of the single-GPU run and only stage 2 is
+    // bjacobi.  Grids above amg_gather_cells keep their top levels distributed over the slabs (tp_amg.hip);
+    // smaller ones are replicated from the top: every rank gathers the scalar stage-1 operators.
     const GridDev gam = c->dist ? c->gfull : make_grid(c->g.n0, c->g.n1, c->g.n2, c->g.n2, 0);
     if (!c->amg_p) {
         double st[3];
@@ -72,13 +73,14 @@ void pc_setup(tp_ctx *c) {
                 sg[a] = n[a] > 1 ? c->vol / (hh * hh) : 0.0;
             }
             amg_build(c, c->amg_T, gam, sg);
+            TP_REQUIRE((c->amg_p->dist_levels > 0) == (c->amg_T->dist_levels > 0), "stage-1 hierarchies disagree on distribution");
         }
     }
     Stencil Sl;
     Sl.base = c->Sm.p;
     Sl.slot_stride = c->g.ntot;
     if (cptr) TP_REQUIRE(c->Sm.p, "pc_cptr needs the S~ operator (assemble with want_schur)");
-    if (c->dist) {
+    if (c->dist && c->amg_p->dist_levels == 0) {
         const size_t ng = (size_t)c->gfull.ntot;
         if (c->gA00.n < 7 * ng) {
             c->gA00.alloc(7 * ng);
@@ -109,7 +111,7 @@ void pc_setup(tp_ctx *c) {
                              (uintptr_t)c->Sm.p, (uintptr_t)c->ilu.fwd.p, (uintptr_t)c->amg_p, (uintptr_t)c->amg_T,
                              (uintptr_t)c->w1.p, (uintptr_t)c->w3.p, (uintptr_t)c->w4.p, (uintptr_t)c->dcoef.p,
                              (uintptr_t)c->opt.amg_nu, (uintptr_t)c->opt.pc_kind, (uintptr_t)c->opt.decoup,
-                             (uintptr_t)c->opt.amg_single, (uintptr_t)c->opt.amg_full_levels, (uintptr_t)c->opt.amg_coarse_pre, (uintptr_t)c->opt.amg_coarse_post,
+                             (uintptr_t)c->opt.amg_single, (uintptr_t)c->opt.amg_gather_cells, (uintptr_t)c->opt.amg_full_levels, (uintptr_t)c->opt.amg_coarse_pre, (uintptr_t)c->opt.amg_coarse_post,
                              (uintptr_t)c->ilu.ntiles, (uintptr_t)c->ilu.nsteps};
     uintptr_t h = 1469598103934665603ull;
     for (uintptr_t v : sig) h = (h ^ v) * 1099511628211ull;
@@ -130,7 +132,7 @@ void stage1_apply(tp_ctx *c, const double *x, double *y) {
         TP_REQUIRE(c->b == 3, "pc_cptr is a two-phase preconditioner");
         stage1_rhs(c, x, 1, r1);
     }
-    if (c->dist) {
+    if (c->dist && c->amg_p->dist_levels == 0) {
         // gathered global system: work vectors gr0, gr1, gy0, gy1, gt, gw on the global grid
         const GridDev &G = c->gfull;
         const long ng = G.ntot;
@@ -160,10 +162,13 @@ void stage1_apply(tp_ctx *c, const double *x, double *y) {
         return;
     }
     // PCFIELDSPLIT schur FULL on (p,T) (twophase.py:536-545): K(A00), K(S~) = one V-cycle each
+    // (multi-GPU with distributed AMG levels: the V-cycles return owned cells, the couplings read halos)
     double *y0 = y, *y1 = y + nt;
     amg_vcycle(c, c->amg_p, r0, c->w4.p);                                   // y0 = K(A00) r0
+    if (c->dist) halo_exchange(c, g, c->w4.p, 1, nt);
     spmv_scalar(c, g, c->opA10, c->w4.p, t, -1.0, r1);                      // t = r1 - A10 y0
     amg_vcycle(c, c->amg_T, t, y1);                                         // y1 = K(S~) t
+    if (c->dist) halo_exchange(c, g, y1, 1, nt);
     spmv_scalar(c, g, c->opA01, y1, t, -1.0, r0);                           // t = r0 - A01 y1
     amg_vcycle(c, c->amg_p, t, y0);                                         // y0 = K(A00) t
 }
@@ -171,7 +176,8 @@ void stage1_apply(tp_ctx *c, const double *x, double *y) {
 // composite multiplicative: y = B1 x ; r = x - J y ; y += B2 r
 static void pc_apply_body(tp_ctx *c, const double *x, double *y) {
     const int npri = c->opt.pc_kind == 1 ? 2 : 1;
-    stage1_apply(c, x, y);       // multi-GPU: y comes back with live halo planes
+    stage1_apply(c, x, y);       // multi-GPU, replicated stage 1: y comes back with live halo planes
+    if (c->dist && c->amg_p->dist_levels > 0) halo_exchange(c, c->g, y, npri, c->g.ntot);
     resid_block_cols(c, c->J.p, x, y, npri, c->w1.p);        // secondary fields of y are zero
     ilu_solve(c, c->w1.p, y, y);                             // y = y + M^-1 r
 }

@@ -45,7 +45,7 @@ class tp_options(C.Structure):
                 ("amg_omega", C.c_double), ("amg_nu", C.c_int32), ("amg_min_cells", C.c_int32),
                 ("ilu_t1", C.c_int32), ("ilu_t2", C.c_int32), ("ilu_t0", C.c_int32),
                 ("amg_full_levels", C.c_int32), ("amg_coarse_pre", C.c_int32), ("amg_coarse_post", C.c_int32),
-                ("amg_single", C.c_int32)]
+                ("amg_single", C.c_int32), ("amg_gather_cells", C.c_int32)]
 
 
 class tp_solve_info(C.Structure):
@@ -62,7 +62,7 @@ API_SYMBOLS = (
     "tp_residual", "tp_jacobian", "tp_get_residual", "tp_export_jacobian", "tp_export_schur",
     "tp_well_rates", "tp_vec_create", "tp_vec_set", "tp_vec_get", "tp_vec_copy_residual", "tp_spmv", "tp_pc_setup",
     "tp_pc_apply", "tp_stage1_update", "tp_stage1_apply", "tp_ilu0_factor", "tp_ilu0_solve", "tp_amg_setup",
-    "tp_amg_vcycle", "tp_schur_apply", "tp_fgmres", "tp_newton_solve", "tp_time_kernel", "tp_amg_info",
+    "tp_amg_vcycle", "tp_schur_apply", "tp_fgmres", "tp_newton_solve", "tp_time_kernel", "tp_amg_info", "tp_amg_layout",
 )
 
 DEFAULT_OPTS = dict(
@@ -70,6 +70,7 @@ DEFAULT_OPTS = dict(
     ksp_rtol=1e-7, ksp_atol=1e-50, ksp_max_it=200, ksp_restart=200,
     snes_rtol=1e-8, snes_atol=1e-50, snes_stol=1e-8, snes_max_it=15,
     amg_omega=0.8, amg_min_cells=64, amg_nu=2, amg_full_levels=3, amg_coarse_pre=0, amg_coarse_post=2, amg_single=False,
+    amg_gather_cells=2000000,
     ilu_tile=(1 << 30, 8, 8),
 )
 
@@ -170,7 +171,7 @@ class HipEngine:
                           o["ksp_restart"], o["snes_rtol"], o["snes_atol"], o["snes_stol"], o["snes_max_it"],
                           o["amg_omega"], o["amg_nu"], o["amg_min_cells"], int(min(t[1], 64)), int(min(t[2], 64)),
                           0 if t[0] >= (1 << 30) else int(t[0]), int(o["amg_full_levels"]), int(o["amg_coarse_pre"]),
-                          int(o["amg_coarse_post"]), int(bool(o["amg_single"])))
+                          int(o["amg_coarse_post"]), int(bool(o["amg_single"])), int(o["amg_gather_cells"]))
 
     def set_options(self, **kw):
         self.opts.update(kw)
@@ -348,6 +349,13 @@ class HipEngine:
         nl, oc = C.c_int32(), C.c_double()
         self._ck(self.lib.tp_amg_info(self.ctx, which, C.byref(nl), C.byref(oc)))
         return nl.value, oc.value
+
+    def amg_layout(self, which=0):
+        """(number of slab-distributed top levels, coarsening axis of every level)."""
+        nd, na = C.c_int32(), C.c_int32()
+        axes = (C.c_int32*64)()
+        self._ck(self.lib.tp_amg_layout(self.ctx, which, C.byref(nd), axes, 64, C.byref(na)))
+        return nd.value, [axes[i] for i in range(min(na.value, 64))]
 
     def newton_solve(self):
         info = tp_solve_info()

@@ -42,7 +42,7 @@ def engine_options(solver_parameters, model_name, decoup="No"):
     o = dict(DEFAULT_OPTS)
     o["decoup"] = decoup
     build_keys = ("amg_omega", "amg_nu", "amg_min_cells", "amg_full_levels", "amg_coarse_pre", "amg_coarse_post", "amg_single",
-                  "ilu_tile")
+                  "amg_gather_cells", "ilu_tile")
     for k in build_keys:
         if k in sp:
             o[k] = sp.pop(k)
