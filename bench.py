@@ -28,7 +28,7 @@ HBM_PEAK_GBS = 8000.0          # MI355X_MICROARCH.md: HBM3E 8 TB/s spec
 SPMV_BYTES_PER_CELL = {(3, 7): 584, (3, 5): 432, (2, 7): 292, (2, 5): 216}
 
 
-def build_case(name, Nxyz=None):
+def build_case(name, Nxyz=None, refine=1):
     """BASELINE configs on synthetic data."""
     from thermalporous_amd.physicalparameters import PhysicalParameters
     from thermalporous_amd.SPE10model3D import SPE10Model3D
@@ -41,7 +41,7 @@ def build_case(name, Nxyz=None):
         Nx, Ny, Nz = Nxyz or (60, 220, 85)
     else:
         raise ValueError(name)
-    geo = SPE10Model3D(Nx, Ny, Nz, params)
+    geo = SPE10Model3D(Nx, Ny, Nz, params, refine=refine)    # refine r: the 60x220x85 field upsampled r-fold (BASELINE config 5: r=4)
     L, Ly, Lz = geo.Length, geo.Length_y, geo.Length_z
     # SPE10 well (x,y) positions (wellcase.py:30-36), producer low / injector high in the column
     prod = [[140.0/365.76*L, 210.0/670.56*Ly, 0.2*Lz]]
@@ -50,9 +50,9 @@ def build_case(name, Nxyz=None):
     return params, geo, case
 
 
-def make_model(name, engine_factory=None, Nxyz=None, maxdt=0.1):
+def make_model(name, engine_factory=None, Nxyz=None, maxdt=0.1, refine=1):
     from thermalporous_amd.twophase import TwoPhase
-    params, geo, case = build_case(name, Nxyz)
+    params, geo, case = build_case(name, Nxyz, refine)
     return TwoPhase(geo, case, params, end=1e9, maxdt=maxdt, small_dt_start=True, solver_parameters="pc_cptr",
                     filename=None, verbosity=False, _engine_factory=engine_factory)
 
