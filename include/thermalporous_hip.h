@@ -64,7 +64,9 @@ typedef struct tp_source {
  * (singlephase.py:289-354, twophase.py:416-433,531-597). */
 typedef struct tp_options {
     int32_t pc_kind;         /* 0 = pc_cpr (CPRStage1PC + bjacobi/ILU0), 1 = pc_cptr (CPTRStage1PC
-                                with fieldsplit Schur FULL, V(App), V(S~)) */
+                                with fieldsplit Schur FULL, V(App), V(S~)), 2 = pc_fieldsplit_cd
+                                (single-phase: fieldsplit Schur FULL on (p,T) with V(App) and the
+                                ConvDiffSchurPC V(S~), no second stage; singlephase.py:309-319) */
     int32_t decoup;          /* 0 "No", 1 "QI", 2 "TI"  (option key sub_0_cpr_decoup) */
     double  ksp_rtol, ksp_atol;
     int32_t ksp_max_it, ksp_restart;

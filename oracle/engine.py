@@ -92,7 +92,7 @@ class OracleEngine:
     def newton_solve(self):
         o = self.opts
         u = self.u
-        want_schur = o["pc"] == "cptr"
+        want_schur = o["pc"] in ("cptr", "fieldsplit_cd")
         F = self.prob.residual(u)
         fnorm = float(np.linalg.norm(F))
         fnorm0 = fnorm

@@ -414,6 +414,13 @@ class TwoStagePC:
             self.At = At
             self.amg_p.setup(At[:, 0, 0])
             self.amg_T.setup(Sm)
+        elif o["pc"] == "fieldsplit_cd":
+            # single-phase block preconditioner (singlephase.py:309-319): the same Schur FULL stage on the
+            # undecoupled (p,T) system with the ConvDiffSchurPC operator (preconditioners.py:11-163); no stage 2
+            assert J.shape[1] == 2 and o["decoup"] == "No"
+            self.At, self.d = decouple(J, "No", [0, 1])
+            self.amg_p.setup(self.At[:, 0, 0])
+            self.amg_T.setup(Sm)
         else:
             raise ValueError(o["pc"])
 
@@ -439,6 +446,8 @@ class TwoStagePC:
 
     def apply(self, x):
         y = self.stage1(x)
+        if self.o["pc"] == "fieldsplit_cd":
+            return y
         r = x - spmv_block(self.J, y)
         return y + self.ilu.solve(r)
 

@@ -75,6 +75,45 @@ def test_python_pc_classes_reproduce_native_pc_apply():
     h.close()
 
 
+def test_fieldsplit_cd_preset_and_pc_classes():
+    """The single-phase pc_fieldsplit_cd preset (singlephase.py:309-319) through SinglePhase.solve(): HIP engine vs
+    oracle engine; and the PCBase-shaped ConvDiffSchurPC / FieldsplitSchurPC objects reproduce tp_pc_apply."""
+    from oracle.engine import OracleEngine
+    from thermalporous_amd import preconditioners as pcs
+    from thermalporous_amd.engine import HipEngine
+    from thermalporous_amd.singlephase import SinglePhase
+    res = []
+    for factory in (OracleEngine, None):
+        spec, u0, p, g, c = cases.c1_homogeneous(N=16)
+        m = SinglePhase(g, c, p, end=2.0, maxdt=1.0, small_dt_start=False, solver_parameters="pc_fieldsplit_cd",
+                        filename=None, verbosity=False, _engine_factory=factory)
+        assert m.engine_opts["pc"] == "fieldsplit_cd"
+        m.solve()
+        res.append((m.nits_vec, m.lits_vec, m.u.dat.data_ro[0].copy(), m.u.dat.data_ro[1].copy()))
+    assert res[0][0] == res[1][0]
+    assert all(abs(a - b) <= 1 for a, b in zip(res[0][1], res[1][1]))
+    assert rel2(res[1][2], res[0][2]) < 1e-8 and rel2(res[1][3], res[0][3]) < 1e-8
+
+    spec, u0, *_ = cases.c4_spe10_3d(Nx=7, Ny=9, Nz=6, nphase=1)
+    h = HipEngine(spec, dict(pc="fieldsplit_cd"))
+    u = cases.perturbed_state(spec, seed=9, amp=0.3)
+    h.set_old(u0)
+    h.set_dt(4000.0)
+    h.set_state(u)
+    h.jacobian()
+    pc = pcs.PC(h, {"decoup": "No"}, prefix="fieldsplit_1_")
+    fs = pcs.FieldsplitSchurPC(pcs.ConvDiffSchurPC())
+    fs.setUp(pc)
+    x = np.random.default_rng(2).standard_normal((2,) + spec["phi"].shape)
+    h.vec_set("x", x)
+    fs.apply(pc, "x", "y_py")
+    h.pc_apply("x", "y_native")
+    assert rel2(h.vec_get("y_py"), h.vec_get("y_native")) < 1e-12
+    with pytest.raises(NotImplementedError):
+        pcs.ConvDiffSchurTwoPhasesPC().setUp(pc)      # the two-phase S~ belongs to pc_cptr
+    h.close()
+
+
 def test_full_size_properties_c4():
     """BASELINE config 4 at full size (60x220x85): size-independent properties of the GPU path --
     pairwise cancellation of the face fluxes, linearity of every preconditioner stage, and the true

@@ -41,6 +41,9 @@ CASES = [
     ("c4_2ph_3d_tiles", cases.c4_spe10_3d, dict(Nx=11, Ny=13, Nz=17, nphase=2), dict(pc="cptr", ilu_tile=(5, 4, 7))),
     ("c4_2ph_3d_fp32amg", cases.c4_spe10_3d, dict(Nx=9, Ny=14, Nz=8, nphase=2), dict(pc="cptr", amg_single=True)),
     ("c4_2ph_3d_v22", cases.c4_spe10_3d, dict(Nx=9, Ny=14, Nz=8, nphase=2), dict(pc="cptr", amg_full_levels=99)),
+    # single-phase block preconditioner pc_fieldsplit_cd (singlephase.py:309-319): ConvDiffSchurPC operator
+    ("c4_1ph_3d_fscd", cases.c4_spe10_3d, dict(Nx=7, Ny=13, Nz=9, nphase=1), dict(pc="fieldsplit_cd")),
+    ("c2_1ph_2d_fscd", cases.c3_spe10_2d, dict(Nx=14, Ny=19, nphase=1), dict(pc="fieldsplit_cd")),
 ]
 
 
@@ -56,7 +59,7 @@ def test_assembly_parity(name, builder, kw, opts):
     Rh = h.residual()
     for f in range(o.b):
         assert relmax(Rh[f], Ro[f]) < 1e-11, (name, "residual field", f)
-    schur = opts["pc"] == "cptr"
+    schur = opts["pc"] in ("cptr", "fieldsplit_cd")
     out_o = o.jacobian(want_schur=schur)
     out_h = h.jacobian(want_schur=schur)
     Jo, Jh = (out_o[0], out_h[0]) if schur else (out_o, out_h)
@@ -86,7 +89,7 @@ def test_linear_stages_parity(name, builder, kw, opts):
         e.set_old(u0)
         e.set_dt(8640.0)
         e.set_state(u)
-    schur = opts["pc"] == "cptr"
+    schur = opts["pc"] in ("cptr", "fieldsplit_cd")
     out = o.jacobian(want_schur=schur)
     J, Sm = out if schur else (out, None)
     h.jacobian()
@@ -130,6 +133,7 @@ NEWTON = [
     ("c1", cases.c1_homogeneous, dict(N=12, nphase=1), dict(pc="cpr", ilu_tile=(1 << 30, 64, 1)), 86400.0),
     ("c3", cases.c3_spe10_2d, dict(Nx=14, Ny=19, nphase=2), dict(pc="cptr", ksp_rtol=1e-8, snes_max_it=25, ilu_tile=(1 << 30, 64, 1)), 864.0),
     ("c4", cases.c4_spe10_3d, dict(Nx=7, Ny=13, Nz=9, nphase=2), dict(pc="cptr", ksp_rtol=1e-8, snes_max_it=25), 86.4),
+    ("c4_1ph_fscd", cases.c4_spe10_3d, dict(Nx=7, Ny=13, Nz=9, nphase=1), dict(pc="fieldsplit_cd", ksp_rtol=1e-8), 864.0),
 ]
 
 

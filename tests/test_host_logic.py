@@ -129,8 +129,16 @@ def test_solver_option_mapping_and_rejections():
                   filename=None, verbosity=False, _engine_factory=OracleEngine)
     assert m2.engine_opts["pc"] == "cptr" and m2.engine_opts["ksp_rtol"] == 1e-8 and m2.engine_opts["snes_max_it"] == 25
     assert m2.i_S_o == 2 and m2.appctx["saturation_space"] == 2
+    m3 = SinglePhase(g, c, p, solver_parameters="pc_fieldsplit_cd", filename=None, verbosity=False,
+                     _engine_factory=OracleEngine)
+    assert m3.engine_opts["pc"] == "fieldsplit_cd" and m3.engine_opts["decoup"] == "No"
+    with pytest.raises(NotImplementedError):     # selfp / a11 Schur preconditioning are not on the path
+        engine_options({"pc_type": "fieldsplit", "pc_fieldsplit_type": "schur", "pc_fieldsplit_schur_fact_type": "FULL",
+                        "pc_fieldsplit_schur_precondition": "selfp"}, "Single phase")
+    with pytest.raises(NotImplementedError):     # the single-phase block PC does not exist for two phases
+        engine_options(m3.solver_parameters, "Two-phase")
     with pytest.raises(NotImplementedError):
-        SinglePhase(g, c, p, solver_parameters="pc_fieldsplit_cd", filename=None, _engine_factory=OracleEngine)
+        SinglePhase(g, c, p, solver_parameters="pc_fieldsplit_selfp", filename=None, _engine_factory=OracleEngine)
     with pytest.raises(NotImplementedError):
         TwoPhase(g, c, p2, solver_parameters="pc_cptramg_QI", filename=None, _engine_factory=OracleEngine)
     with pytest.raises(NotImplementedError):
@@ -144,6 +152,20 @@ def test_solver_option_mapping_and_rejections():
          "sub_0_cpr_stage1": {"ksp_type": "preonly", "pc_type": "hypre", "pc_hypre_type": "boomeramg"},
          "sub_1_pc_bjacobi_blocks": 1, "sub_1_sub_pc_type": "ilu", "sub_1_sub_pc_factor_levels": 0, "mat_type": "aij"}
     assert engine_options(d, "Single phase")["pc"] == "cpr"
+
+
+def test_fieldsplit_cd_oracle_time_loop():
+    """pc_fieldsplit_cd (singlephase.py:309-319) drives BASELINE config 1 to the same state as pc_cpr."""
+    sols = []
+    for preset in ("pc_cpr", "pc_fieldsplit_cd"):
+        spec, u0, p, g, c = cases.c1_homogeneous(N=10)
+        m = SinglePhase(g, c, p, end=2.0, maxdt=1.0, small_dt_start=False, solver_parameters=preset,
+                        filename=None, verbosity=False, _engine_factory=OracleEngine)
+        m.solve()
+        assert m.failed_solves == 0
+        sols.append([m.u.dat.data_ro[f].copy() for f in range(2)])
+    for f in range(2):
+        assert np.linalg.norm(sols[0][f] - sols[1][f]) <= 1e-6*np.linalg.norm(sols[0][f])
 
 
 def test_config1_time_loop_with_oracle_engine(tmp_path):

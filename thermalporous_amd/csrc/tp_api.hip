@@ -277,7 +277,7 @@ int tp_create(const tp_grid *grid, const tp_params *prm, const tp_options *opt, 
     for (int a = 0; a < 3; ++a) { c->K[a].alloc(nt); c->TK[a].alloc(nt); }
     c->u.alloc(B * nt); c->u_old.alloc(B * nt); c->acc_old.alloc(B * nt); c->R.alloc(B * nt);
     c->J.alloc(7 * B * B * nt);
-    if (opt->pc_kind == 1) c->Sm.alloc(7 * nt);
+    if (schur_of(*opt)) c->Sm.alloc(7 * nt);
     *out = c;
     TP_API_END
 }
@@ -301,7 +301,7 @@ int tp_set_options(tp_ctx *c, const tp_options *opt) {
     c->opt = *opt;
     if (tile_changed) c->ilu.slots = 0;
     if (amg_changed) { delete c->amg_p; c->amg_p = nullptr; delete c->amg_T; c->amg_T = nullptr; }
-    if (opt->pc_kind == 1 && c->Sm.n == 0) c->Sm.alloc((size_t)7 * c->g.ntot);
+    if (schur_of(*opt) && c->Sm.n == 0) c->Sm.alloc((size_t)7 * c->g.ntot);
     c->pc_ready = false;
     TP_API_END
 }
@@ -488,7 +488,7 @@ int tp_residual(tp_ctx *c, double *norm2_out) {
 int tp_jacobian(tp_ctx *c) {
     TP_API_BEGIN
     if (c->dist) halo_exchange(c, c->g, c->u.p, c->b, c->g.ntot);
-    assemble(c, true, c->opt.pc_kind == 1);
+    assemble(c, true, schur_of(c->opt));
     c->pc_ready = false;
     TP_HIP(hipStreamSynchronize(c->stream));
     TP_API_END
@@ -675,7 +675,7 @@ int tp_time_kernel(tp_ctx *c, int32_t which, int32_t reps, double *ms_avg) {
                 if (c->dist && c->amg_p->dist_levels == 0) amg_vcycle(c, c->amg_p, c->gvec.p, c->gvec.p + 2 * c->gfull.ntot);   // global-grid buffers
                 else amg_vcycle(c, c->amg_p, c->R.p, c->w2.p);
                 break;
-            case 3: assemble(c, true, c->opt.pc_kind == 1); break;
+            case 3: assemble(c, true, schur_of(c->opt)); break;
             case 4: pc_apply(c, c->R.p, c->dx.p); break;
             case 5: pc_setup(c); break;
             case 6: ilu_factor(c); break;

@@ -68,6 +68,11 @@ inline dim3 xcd_grid(long n, int bs = 256) {
     return dim3((unsigned)(((nb + 7) / 8) * 8));
 }
 
+// pc_kind: 0 pc_cpr, 1 pc_cptr, 2 pc_fieldsplit_cd.  The last two run the fieldsplit-Schur-FULL stage on (p,T)
+// and need the S~ operator from the assembly.
+inline int npri_of(const tp_options &o) { return o.pc_kind >= 1 ? 2 : 1; }
+inline bool schur_of(const tp_options &o) { return o.pc_kind >= 1; }
+
 // Scalar 7-point stencil operator: slot s lives at base + s*slot_stride (doubles).
 struct Stencil {
     double *base = nullptr;

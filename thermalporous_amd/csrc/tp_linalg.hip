@@ -361,7 +361,7 @@ __global__ void k_decoup_apply(GridDev g, const double *J, int npri, const doubl
 
 void decouple(tp_ctx *c) {
     const GridDev &g = c->g;
-    const int npri = c->opt.pc_kind == 1 ? 2 : 1;
+    const int npri = npri_of(c->opt);
     const long nt = g.ntot;
     const int B = c->b;
     if (c->opt.decoup == 0) {

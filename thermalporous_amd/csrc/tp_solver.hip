@@ -19,7 +19,8 @@ namespace tp {
 // ------------------------------------------------------------------------------------------------
 static void ensure_work(tp_ctx *c) {
     const size_t nv = (size_t)c->b * c->g.ntot;
-    if (c->w1.n < nv) { c->w1.alloc(nv); c->w2.alloc(nv); c->w3.alloc(nv); c->w4.alloc(nv); }
+    // w3 holds the Schur stage's r0, r1 and t: three planes even for the 2-field single-phase system
+    if (c->w1.n < nv) { c->w1.alloc(nv); c->w2.alloc(nv); c->w3.alloc(std::max(nv, (size_t)3 * c->g.ntot)); c->w4.alloc(nv); }
 }
 
 // mean interior-face transmissibility per axis over the GLOBAL grid (sum/count all-reduced over slabs)
@@ -53,7 +54,12 @@ static void face_strengths(tp_ctx *c, double st[3]) {
 void pc_setup(tp_ctx *c) {
     TP_REQUIRE(c->jac_ready, "pc_setup needs an assembled Jacobian");
     ensure_work(c);
-    const bool cptr = c->opt.pc_kind == 1;
+    const bool cptr = schur_of(c->opt);       // fieldsplit-Schur stage on (p,T): pc_cptr and pc_fieldsplit_cd
+    if (c->opt.pc_kind == 1) TP_REQUIRE(c->b == 3, "pc_cptr is a two-phase preconditioner");
+    if (c->opt.pc_kind == 2) {
+        TP_REQUIRE(c->b == 2, "pc_fieldsplit_cd is a single-phase preconditioner (singlephase.py:309-319)");
+        TP_REQUIRE(c->opt.decoup == 0, "pc_fieldsplit_cd has no decoupling stage");
+    }
     // stage 1: decoupling + AMG hierarchies (CPRStage1PC.update / CPTRStage1PC.update)
     decouple(c);
     // single GPU: the AMG works on the slab (= whole grid).  Multi-GPU: the hierarchy is that of the GLOBAL grid,
@@ -123,15 +129,12 @@ void stage1_apply(tp_ctx *c, const double *x, double *y) {
     const GridDev &g = c->g;
     const long nt = g.ntot;
     ensure_work(c);
-    double *r0 = c->w3.p, *r1 = c->w3.p + nt, *t = c->w3.p + 2 * nt;   // w3 has >= 2 planes; t only for b=3
+    double *r0 = c->w3.p, *r1 = c->w3.p + nt, *t = c->w3.p + 2 * nt;   // w3 has >= 3 planes
     // y_s = 0 for the non-primary fields (:902-903, :1566-1567)
-    const int npri = c->opt.pc_kind == 1 ? 2 : 1;
+    const int npri = npri_of(c->opt);
     for (int f = npri; f < c->b; ++f) vec_zero(c, y + (long)f * nt, nt);
     stage1_rhs(c, x, 0, r0);                       // r_p = x_p - (D_ps D_ss^-1) x_s
-    if (npri == 2) {
-        TP_REQUIRE(c->b == 3, "pc_cptr is a two-phase preconditioner");
-        stage1_rhs(c, x, 1, r1);
-    }
+    if (npri == 2) stage1_rhs(c, x, 1, r1);
     if (c->dist && c->amg_p->dist_levels == 0) {
         // gathered global system: work vectors gr0, gr1, gy0, gy1, gt, gw on the global grid
         const GridDev &G = c->gfull;
@@ -175,9 +178,10 @@ void stage1_apply(tp_ctx *c, const double *x, double *y) {
 
 // composite multiplicative: y = B1 x ; r = x - J y ; y += B2 r
 static void pc_apply_body(tp_ctx *c, const double *x, double *y) {
-    const int npri = c->opt.pc_kind == 1 ? 2 : 1;
+    const int npri = npri_of(c->opt);
     stage1_apply(c, x, y);       // multi-GPU, replicated stage 1: y comes back with live halo planes
     if (c->dist && c->amg_p->dist_levels > 0) halo_exchange(c, c->g, y, npri, c->g.ntot);
+    if (c->opt.pc_kind == 2) return;                          // pc_fieldsplit_cd: the Schur stage IS the preconditioner
     resid_block_cols(c, c->J.p, x, y, npri, c->w1.p);        // secondary fields of y are zero
     ilu_solve(c, c->w1.p, y, y);                             // y = y + M^-1 r
 }
@@ -189,7 +193,7 @@ static void pc_apply_body(tp_ctx *c, const double *x, double *y) {
 void pc_apply(tp_ctx *c, const double *x, double *y) {
     TP_REQUIRE(c->pc_ready, "pc_apply before pc_setup");
     static const bool use_graph = !(getenv("TP_GRAPH") && atoi(getenv("TP_GRAPH")) == 0);
-    c->vcycles += c->opt.pc_kind == 1 ? 3 : 1;
+    c->vcycles += schur_of(c->opt) ? 3 : 1;
     if (!use_graph || c->dist) {
         pc_apply_body(c, x, y);
         return;
@@ -316,7 +320,7 @@ void newton(tp_ctx *c, tp_solve_info *info) {
     const int B = c->b;
     const long nv = (long)B * g.ntot;
     ensure_work(c);
-    const bool schur = c->opt.pc_kind == 1;
+    const bool schur = schur_of(c->opt);
     if (schur && c->Sm.n < (size_t)7 * g.ntot) c->Sm.alloc((size_t)7 * g.ntot);
     TP_REQUIRE(c->u.n > 0, "state not set");
     tp::DBuf<double> *dx = &c->dx;

@@ -74,7 +74,7 @@ DEFAULT_OPTS = dict(
     ilu_tile=(1 << 30, 8, 8),
 )
 
-_PC = {"cpr": 0, "cptr": 1}
+_PC = {"cpr": 0, "cptr": 1, "fieldsplit_cd": 2}
 _DECOUP = {"No": 0, "QI": 1, "TI": 2}
 
 
@@ -261,8 +261,8 @@ class HipEngine:
     def jacobian(self, u=None, want_schur=False):
         if u is not None:
             self.set_state(u)
-        if want_schur and self.opts["pc"] != "cptr":
-            raise EngineError("S~ is assembled only for pc='cptr'")
+        if want_schur and self.opts["pc"] not in ("cptr", "fieldsplit_cd"):
+            raise EngineError("S~ is assembled only for pc='cptr' / 'fieldsplit_cd'")
         self._ck(self.lib.tp_jacobian(self.ctx))
         b = self.b
         out = np.empty(7*b*b*self.ntot)

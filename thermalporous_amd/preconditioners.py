@@ -23,6 +23,8 @@ PCCOMPOSITE multiplicative("python,bjacobi") from the pieces.
 """
 
 
+import numpy as np
+
 class PC():
     """Minimal stand-in for the petsc4py PC handed to PCBase methods."""
 
@@ -101,9 +103,11 @@ class ConvDiffSchurTwoPhasesPC(PCBase):
     """Schur-complement approximation S~ = temperature convection-diffusion operator frozen at the
     current Newton state (:165-333); assembled by the fused assembly kernel as a by-product."""
 
+    needs = "cptr"
+
     def initialize(self, pc):
-        if pc.engine.opts["pc"] != "cptr":
-            raise NotImplementedError("S~ is assembled for pc_cptr only")
+        if pc.engine.opts["pc"] != self.needs:
+            raise NotImplementedError("this S~ is assembled for pc=%r only" % self.needs)
         self.update(pc)
 
     def update(self, pc):
@@ -116,11 +120,51 @@ class ConvDiffSchurTwoPhasesPC(PCBase):
 
 
 class ConvDiffSchurPC(ConvDiffSchurTwoPhasesPC):
-    """Single-phase variant (:11-163), used by the reference's pc_fieldsplit_cd preset
-    (singlephase.py:309-319), which is listed as a 'next' row."""
+    """Single-phase variant (:11-163): S~ = accumulation + upwinded advection of c_v rho/mu T + conduction
+    - producer / heater source derivatives, frozen at the Newton state.  The Schur block of the
+    reference's pc_fieldsplit_cd preset (singlephase.py:309-319); one V-cycle per application."""
+    needs = "fieldsplit_cd"
 
-    def initialize(self, pc):
-        raise NotImplementedError("pc_fieldsplit_cd (single-phase block preconditioner) is not on the hot path yet")
+
+class FieldsplitSchurPC():
+    """PCFIELDSPLIT schur FULL on (p,T) with K(A00) = V-cycle and K(S) = the given Schur PC
+    (singlephase.py:309-319; the same three solves as pc_cptr's stage 1, twophase.py:536-545):
+        y0 = K(A00) x0 ;  y1 = K(S)(x1 - A10 y0) ;  y0 = K(A00)(x0 - A01 y1).
+    Assembled from the stage objects so tests can show that it reproduces tp_pc_apply."""
+
+    def __init__(self, schur_pc):
+        self.schur = schur_pc
+
+    def setUp(self, pc):
+        self.schur.setUp(pc)
+
+    def apply(self, pc, x, y):
+        eng = pc.engine
+        xh = eng.vec_get(x)
+        eng.amg_vcycle(0, x, 0, "_fs_w", 0)
+        y0 = eng.vec_get("_fs_w")[0]
+        # couplings through MatMult on a vector with one live field (decoupling "No": A10, A01 are blocks of J)
+        z = np.zeros_like(xh)
+        z[0] = y0
+        eng.vec_set("_fs_w", z)
+        eng.spmv("_fs_w", "_fs_t")
+        t = xh.copy()
+        t[1] = xh[1] - eng.vec_get("_fs_t")[1]                     # x1 - A10 y0
+        eng.vec_set("_fs_t", t)
+        self.schur.apply(pc, "_fs_t", "_fs_w")                     # y1 = K(S~)(...)
+        y1 = eng.vec_get("_fs_w")[1]
+        z[:] = 0.0
+        z[1] = y1
+        eng.vec_set("_fs_w", z)
+        eng.spmv("_fs_w", "_fs_t")
+        t = xh.copy()
+        t[0] = xh[0] - eng.vec_get("_fs_t")[0]                     # x0 - A01 y1
+        eng.vec_set("_fs_t", t)
+        eng.amg_vcycle(0, "_fs_t", 0, "_fs_w", 0)
+        out = np.zeros_like(xh)
+        out[0] = eng.vec_get("_fs_w")[0]
+        out[1] = y1
+        eng.vec_set(y, out)
 
 
 class CompositePC():

@@ -67,9 +67,18 @@ class SinglePhase(ThermalModel):
                   "sub_1_sub_pc_type": "ilu",
                   "sub_1_sub_pc_factor_levels": 0,
                   "mat_type": "aij"}
+        pc_fieldsplit_cd = {"pc_type": "fieldsplit",     # (:309-319) the block preconditioner of Roy et al. 2019
+                            "pc_fieldsplit_type": "schur",
+                            "pc_fieldsplit_schur_fact_type": "FULL",
+                            "fieldsplit_0": v_cycle,
+                            "fieldsplit_1_ksp_type": "preonly",
+                            "fieldsplit_1_pc_type": "python",
+                            "fieldsplit_1_pc_python_type": "thermalporous.preconditioners.ConvDiffSchurPC",
+                            "fieldsplit_1_schur": v_cycle}
         presets = {"pc_cpr": pc_cpr,
                    "pc_cpr_QI": {**pc_cpr, "sub_0_cpr_decoup": "QI"},      # (:353)
-                   "pc_cpr_TI": {**pc_cpr, "sub_0_cpr_decoup": "TI"}}      # (:354)
+                   "pc_cpr_TI": {**pc_cpr, "sub_0_cpr_decoup": "TI"},      # (:354)
+                   "pc_fieldsplit_cd": pc_fieldsplit_cd}
         parameters = newton
         if self.solver_parameters is None:
             # the reference's default name "pc_fieldsplit" matches no branch (:410-439) and silently runs

@@ -57,6 +57,21 @@ def engine_options(solver_parameters, model_name, decoup="No"):
                          ("snes_rtol", "snes_rtol"), ("snes_atol", "snes_atol"), ("snes_stol", "snes_stol")):
         if k_src in sp:
             o[k_dst] = sp[k_src]
+    if sp.get("pc_type") == "fieldsplit":
+        # pc_fieldsplit_cd (singlephase.py:309-319): Schur FULL on (p,T), V-cycle on A_pp, ConvDiffSchurPC on S
+        if sp.get("pc_fieldsplit_type") != "schur" or str(sp.get("pc_fieldsplit_schur_fact_type", "")).upper() != "FULL" \
+                or not str(sp.get("fieldsplit_1_pc_python_type", "")).endswith("ConvDiffSchurPC"):
+            raise NotImplementedError("the only fieldsplit preconditioner on the hot path is pc_fieldsplit_cd "
+                                      "(schur FULL with ConvDiffSchurPC); selfp/a11 variants are not")
+        if model_name == "Two-phase":
+            raise NotImplementedError("pc_fieldsplit_cd is the single-phase block preconditioner")
+        if o["decoup"] != "No":
+            raise NotImplementedError("pc_fieldsplit_cd has no decoupling stage")
+        o["pc"] = "fieldsplit_cd"
+        for k in sp:
+            if not (k in _IGNORED or k.startswith(("fieldsplit_", "pc_", "ksp_", "snes_"))):
+                raise KeyError("unknown solver parameter %r" % k)
+        return o
     if sp.get("pc_type") != "composite" or sp.get("pc_composite_type", "multiplicative") != "multiplicative" \
             or sp.get("pc_composite_pcs") != "python,bjacobi":
         raise NotImplementedError(
