@@ -192,3 +192,29 @@ def test_slab_group_matches_single_slab_and_oracle(name, builder, kw, opts, dts,
     for f in range(u_ref.shape[0]):
         assert rel2(u_n[f], u_ref[f]) < 1e-7
         assert rel2(u_n[f], o.get_state()[f]) < 1e-7
+
+
+@pytest.mark.parametrize("gather", [2000000, 0], ids=["replicated", "distributed"])
+def test_rccl_calls_on_a_one_rank_communicator(gather):
+    """RCCL refuses two ranks on one GPU, so the N-rank exchange cannot be rehearsed on this box; a ONE-rank
+    communicator still runs every RCCL entry point the slab path uses (ncclCommInitRank, grouped send/recv with
+    no neighbours, grouped in-place ncclBroadcast gathers, ncclAllReduce on the compute stream) and must change
+    nothing in the results."""
+    from thermalporous_amd.engine import HipEngine
+    spec, u0, *_ = cases.c4_spe10_3d(Nx=8, Ny=21, Nz=7, nphase=2)
+    opts = dict(pc="cptr", ksp_rtol=1e-8, snes_max_it=25, amg_gather_cells=gather)
+    res = []
+    for boot in (None, lambda make_id: make_id()):
+        h = HipEngine(spec, opts, rank=0, nranks=1, comm_bootstrap=boot)
+        h.set_state(u0)
+        infos = []
+        for dt in (40.0, 80.0):
+            h.set_old(None)
+            h.set_dt(dt)
+            infos.append(h.newton_solve())
+        res.append(([(i["nits"], i["lits"], i["reason"]) for i in infos], h.get_state(), h.amg_layout(0)[0]))
+        h.close()
+    assert res[0][0] == res[1][0] and all(r[2] > 0 for r in res[0][0])
+    assert res[0][2] == 0 and (res[1][2] > 0) == (gather == 0)
+    for f in range(3):
+        assert rel2(res[1][1][f], res[0][1][f]) < 1e-9

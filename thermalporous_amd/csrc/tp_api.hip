@@ -318,7 +318,7 @@ int tp_comm_unique_id(void *id128) {
 int tp_comm_init(tp_ctx *c, const void *id128) {
     TP_API_BEGIN
     TP_REQUIRE(c && id128, "null argument");
-    TP_REQUIRE(c->grid.nranks > 1, "tp_comm_init on a single-slab context");
+    TP_REQUIRE(c->grid.nranks >= 1, "bad nranks");     // a 1-rank communicator is legal (exercises the RCCL calls on one GPU)
     TP_HIP(hipSetDevice(c->device));
     ncclUniqueId id;
     std::memcpy(&id, id128, sizeof(id));

@@ -139,7 +139,9 @@ class HipEngine:
         if self.nranks > 1 and local_group is not None:
             # N engines in N threads of this process sharing one GPU (validation of the slab algorithm)
             self._ck(self.lib.tp_comm_init_local(self.ctx, local_group))
-        elif self.nranks > 1:
+        elif self.nranks > 1 or comm_bootstrap is not None:
+            # (nranks == 1 with an explicit bootstrap: a one-rank RCCL communicator, used by the tests to run the
+            # library's RCCL calls for real on a one-GPU box)
             if comm_bootstrap is None:
                 raise EngineError("multi-slab engine needs comm_bootstrap(make_id) -> 128-byte id")
             ident = comm_bootstrap(self._unique_id)
