@@ -200,7 +200,7 @@ tp_ctx::~tp_ctx() {
     for (auto *v : vecs) delete v;
     delete amg_p;
     delete amg_T;
-    if (pc_graph) (void)hipGraphExecDestroy(pc_graph);
+    for (auto &gph : pc_graphs) (void)hipGraphExecDestroy(gph.exec);
     if (comm) ncclCommDestroy((ncclComm_t)comm);
     if (ev0) (void)hipEventDestroy(ev0);
     if (ev1) (void)hipEventDestroy(ev1);

@@ -180,8 +180,10 @@ struct tp_ctx {
     // scratch vectors for PC apply
     tp::DBuf<double> w1, w2, w3, w4, dx;
     // captured preconditioner application (hipGraph on fixed staging buffers)
-    tp::DBuf<double> pc_in, pc_out;
-    hipGraphExec_t pc_graph = nullptr;
+    // captured pc_apply graphs, one per (input, output) vector pair: FGMRES applies the preconditioner to basis
+    // vector j into Z_j, a handful of fixed address pairs that recur in every solve
+    struct PcGraph { const double *x; double *y; hipGraphExec_t exec; };
+    std::vector<PcGraph> pc_graphs;
     uint64_t graph_epoch = 1, pc_graph_epoch = 0;
     uintptr_t pc_sig = 0;
     // comm: RCCL communicator (one process per GPU) or an in-process slab group (several contexts on one GPU,

@@ -106,13 +106,21 @@ __global__ __launch_bounds__(64) void k_ilu_factor(IluGeom G, const double *__re
     for (int r = 0; r < B; ++r)
 #pragma unroll
         for (int q = 0; q < B; ++q) Dp[r][q] = 0.0;
-    const long stride[3] = {1, (long)G.g.n0, G.g.np};
     // the Jacobian blocks of a step are gathered one step ahead (their addresses do not depend on the recurrence)
+    // A_mc (the +a block of the lower neighbour m = c - e_a) is NOT loaded: it is the A_up[a] block that the lane
+    // owning m (this lane, lane-1, lane-t1) loaded for the previous step -> taken from its registers by shuffle.
     struct Blk {
-        double D[B][B], Acm[3][B][B], Amc[3][B][B], Aup[3][B][B];
+        double D[B][B], Acm[3][B][B], Aup[3][B][B];
         bool ok, has[3], hasu[3];
     };
     Blk buf[2];
+    double Aprev[3][B][B];                 // A_up of this lane's previous step
+#pragma unroll
+    for (int a = 0; a < 3; ++a)
+#pragma unroll
+        for (int r = 0; r < B; ++r)
+#pragma unroll
+            for (int q = 0; q < B; ++q) Aprev[a][r][q] = 0.0;
     auto load = [&](Blk &k, int s) {
         int l0;
         long c;
@@ -127,7 +135,6 @@ __global__ __launch_bounds__(64) void k_ilu_factor(IluGeom G, const double *__re
 #pragma unroll
                 for (int a = 0; a < 3; ++a) {
                     k.Acm[a][r][q] = k.has[a] ? J[((long)((1 + 2 * a) * B + r) * B + q) * nt + c] : 0.0;
-                    k.Amc[a][r][q] = k.has[a] ? J[((long)((2 + 2 * a) * B + r) * B + q) * nt + c - stride[a]] : 0.0;
                     k.Aup[a][r][q] = k.hasu[a] ? J[((long)((2 + 2 * a) * B + r) * B + q) * nt + c] : 0.0;
                 }
             }
@@ -142,6 +149,15 @@ __global__ __launch_bounds__(64) void k_ilu_factor(IluGeom G, const double *__re
                 Dn[0][r][q] = Dp[r][q];
                 Dn[1][r][q] = __shfl_up(Dp[r][q], 1, 64);
                 Dn[2][r][q] = __shfl_up(Dp[r][q], G.t1, 64);
+            }
+        double Amc[3][B][B];                   // A_mc of the three lower neighbours, from their owners' registers
+#pragma unroll
+        for (int r = 0; r < B; ++r)
+#pragma unroll
+            for (int q = 0; q < B; ++q) {
+                Amc[0][r][q] = Aprev[0][r][q];
+                Amc[1][r][q] = __shfl_up(Aprev[1][r][q], 1, 64);
+                Amc[2][r][q] = __shfl_up(Aprev[2][r][q], G.t1, 64);
             }
         double D[B][B], Di[B][B];
         double *fch = fwd + ((long)tile * ns + s) * (L::PF * 128);
@@ -168,7 +184,7 @@ __global__ __launch_bounds__(64) void k_ilu_factor(IluGeom G, const double *__re
                 for (int q = 0; q < B; ++q) {
                     double v = 0.0;
 #pragma unroll
-                    for (int t = 0; t < B; ++t) v += Bm[r][t] * k.Amc[a][t][q];
+                    for (int t = 0; t < B; ++t) v += Bm[r][t] * Amc[a][t][q];
                     D[r][q] -= v;
                     const int e = (a * B + r) * B + q;
                     fch[(e >> 1) * 128 + lane * 2 + (e & 1)] = Bm[r][q];
@@ -204,6 +220,12 @@ __global__ __launch_bounds__(64) void k_ilu_factor(IluGeom G, const double *__re
                 bch[(e >> 1) * 128 + lane * 2 + (e & 1)] = Di[r][q];
                 Dp[r][q] = Di[r][q];
             }
+#pragma unroll
+        for (int a = 0; a < 3; ++a)
+#pragma unroll
+            for (int r = 0; r < B; ++r)
+#pragma unroll
+                for (int q = 0; q < B; ++q) Aprev[a][r][q] = k.Aup[a][r][q];
     };
     load(buf[0], 0);
     for (int s = 0; s < ns; s += 2) {

@@ -188,8 +188,8 @@ static void pc_apply_body(tp_ctx *c, const double *x, double *y) {
 
 // One preconditioner application is ~100 short kernels (the V-cycles' coarse levels); issued eagerly
 // the host launch path (~3 us per kernel) is slower than the GPU executes them.  The whole sequence
-// is therefore captured ONCE into a hipGraph on fixed staging buffers and replayed per Krylov
-// iteration (two extra vector copies, ~20 us, buy back ~300 us of launch latency).
+// is therefore captured into a hipGraph per (input, output) address pair -- FGMRES uses the fixed pairs
+// (V_j, Z_j) -- and replayed per Krylov iteration.
 void pc_apply(tp_ctx *c, const double *x, double *y) {
     TP_REQUIRE(c->pc_ready, "pc_apply before pc_setup");
     static const bool use_graph = !(getenv("TP_GRAPH") && atoi(getenv("TP_GRAPH")) == 0);
@@ -198,27 +198,30 @@ void pc_apply(tp_ctx *c, const double *x, double *y) {
         pc_apply_body(c, x, y);
         return;
     }
-    const long nv = (long)c->b * c->g.ntot;
-    if (c->pc_in.n < (size_t)nv) { c->pc_in.alloc(nv); c->pc_out.alloc(nv); c->graph_epoch++; }
-    if (!c->pc_graph || c->pc_graph_epoch != c->graph_epoch) {
-        if (c->pc_graph) { (void)hipGraphExecDestroy(c->pc_graph); c->pc_graph = nullptr; }
+    if (c->pc_graph_epoch != c->graph_epoch || c->pc_graphs.size() > 512) {      // stale (or runaway) cache
+        for (auto &gph : c->pc_graphs) (void)hipGraphExecDestroy(gph.exec);
+        c->pc_graphs.clear();
+        c->pc_graph_epoch = c->graph_epoch;
+    }
+    hipGraphExec_t exec = nullptr;
+    for (auto &gph : c->pc_graphs)
+        if (gph.x == x && gph.y == y) { exec = gph.exec; break; }
+    if (!exec) {
         hipGraph_t graph = nullptr;
         TP_HIP(hipStreamBeginCapture(c->stream, hipStreamCaptureModeThreadLocal));
         try {
-            pc_apply_body(c, c->pc_in.p, c->pc_out.p);
+            pc_apply_body(c, x, y);
         } catch (...) {
             (void)hipStreamEndCapture(c->stream, &graph);
             if (graph) (void)hipGraphDestroy(graph);
             throw;
         }
         TP_HIP(hipStreamEndCapture(c->stream, &graph));
-        TP_HIP(hipGraphInstantiate(&c->pc_graph, graph, nullptr, nullptr, 0));
+        TP_HIP(hipGraphInstantiate(&exec, graph, nullptr, nullptr, 0));
         TP_HIP(hipGraphDestroy(graph));
-        c->pc_graph_epoch = c->graph_epoch;
+        c->pc_graphs.push_back({x, y, exec});
     }
-    vec_copy(c, x, c->pc_in.p, nv);
-    TP_HIP(hipGraphLaunch(c->pc_graph, c->stream));
-    vec_copy(c, c->pc_out.p, y, nv);
+    TP_HIP(hipGraphLaunch(exec, c->stream));
 }
 
 // ------------------------------------------------------------------------------------------------
