@@ -141,6 +141,7 @@ struct Amg {
 struct IluData {
     int t0 = 0, t1 = 8, t2 = 8, nt0 = 0, nt1 = 0, nt2 = 0, ntiles = 0, nsteps = 0;
     DBuf<double> fwd, bwd, ytmp;   // streaming factor data in consumption order
+    DBuf<double> jt;               // the Jacobian blocks re-ordered the same way (input of the factorisation)
     long slots = 0;                // ntiles*nsteps*64
 };
 

@@ -65,6 +65,8 @@ template <int B> struct IluLayout {
     static constexpr int PF = (NEF + 1) / 2;              // double2 pairs per forward chunk
     static constexpr int PB = (NEB + 1) / 2;
     static constexpr int PY = (B + 1) / 2;                // pairs of the intermediate vector y
+    static constexpr int NEJ = 7 * B * B;                 // Jacobian entries per cell (7 blocks)
+    static constexpr int PJ = (NEJ + 1) / 2;              // pairs per chunk of the re-ordered Jacobian
 };
 
 // tile/lane/step -> cell; returns false if the lane has no cell at this step
@@ -93,12 +95,51 @@ __device__ __forceinline__ bool tile_cell(const IluGeom &G, const TileInfo &t, i
     return ok;
 }
 
+// Jacobian blocks -> the factorisation's consumption order.  In the plane layout neighbouring lanes of a tile
+// (lane = column (j,k), step = i0 + j + k) sit n0 doubles apart, so a wave touches 64 cache lines per value and
+// uses 8 bytes of each; the ONE wave that factors a tile cannot hide that.  This pass does the same gather with
+// thousands of waves: a workgroup covers ILU_SEG consecutive steps of one (tile, group of entry pairs), so the 16 doubles
+// of every line it touches are consumed by the workgroup itself (L1/L2 hits), and writes chunks
+// [tile][step][entry pair][lane][2] (1 KiB contiguous per wave).  Couplings that leave the tile are written as
+// zeros, so the factorisation needs no masks.
+constexpr int ILU_SEG = 16;      // steps per workgroup
+constexpr int ILU_PPT = 1;       // entry pairs per thread
 template <int B>
-__global__ __launch_bounds__(64) void k_ilu_factor(IluGeom G, const double *__restrict__ J, double *fwd,
+__global__ __launch_bounds__(64 * ILU_SEG) void k_ilu_gather(IluGeom G, const double *__restrict__ J,
+                                                             double *__restrict__ Jt) {
+    using L = IluLayout<B>;
+    const int tile = blockIdx.x, P0 = blockIdx.y * ILU_PPT, s = blockIdx.z * ILU_SEG + (threadIdx.x >> 6),
+              lane = threadIdx.x & 63;
+    const int ns = G.nsteps;
+    if (s >= ns) return;
+    const long nt = G.g.ntot;
+    const TileInfo ti = tile_info(G, tile, lane);
+    int l0;
+    long c;
+    const bool ok = tile_cell(G, ti, s, l0, c);
+    // which of the 7 blocks survive: couplings to cells outside the tile are dropped (bjacobi)
+    const bool keep[7] = {true, l0 > 0, l0 < ti.tt0 - 1, ti.j > 0, ti.j < ti.tj - 1, ti.k > 0, ti.k < ti.tk - 1};
+    double v[2 * ILU_PPT];
+#pragma unroll
+    for (int u = 0; u < 2 * ILU_PPT; ++u) {          // all loads of the thread in flight together
+        const int e = 2 * P0 + u;
+        v[u] = (ok && e < L::NEJ && keep[e / (B * B)]) ? J[(long)e * nt + c] : 0.0;
+    }
+#pragma unroll
+    for (int u = 0; u < ILU_PPT; ++u) {
+        if (P0 + u >= L::PJ) break;
+        double2 o;
+        o.x = v[2 * u];
+        o.y = v[2 * u + 1];
+        reinterpret_cast<double2 *>(Jt + (((long)tile * ns + s) * L::PJ + P0 + u) * 128)[lane] = o;
+    }
+}
+
+template <int B>
+__global__ __launch_bounds__(64) void k_ilu_factor(IluGeom G, const double *__restrict__ Jt, double *fwd,
                                                    double *bwd) {
     using L = IluLayout<B>;
     const int tile = blockIdx.x, lane = threadIdx.x;
-    const long nt = G.g.ntot;
     const TileInfo ti = tile_info(G, tile, lane);
     const int ns = G.nsteps;
     double Dp[B][B];                       // D~^-1 of this lane's previous cell (axis-0 lower neighbour)
@@ -107,11 +148,12 @@ __global__ __launch_bounds__(64) void k_ilu_factor(IluGeom G, const double *__re
 #pragma unroll
         for (int q = 0; q < B; ++q) Dp[r][q] = 0.0;
     // the Jacobian blocks of a step are gathered one step ahead (their addresses do not depend on the recurrence)
+    // The blocks of a step come from the re-ordered Jacobian (k_ilu_gather), one step ahead of their use.
     // A_mc (the +a block of the lower neighbour m = c - e_a) is NOT loaded: it is the A_up[a] block that the lane
     // owning m (this lane, lane-1, lane-t1) loaded for the previous step -> taken from its registers by shuffle.
     struct Blk {
         double D[B][B], Acm[3][B][B], Aup[3][B][B];
-        bool ok, has[3], hasu[3];
+        bool ok;
     };
     Blk buf[2];
     double Aprev[3][B][B];                 // A_up of this lane's previous step
@@ -125,17 +167,23 @@ __global__ __launch_bounds__(64) void k_ilu_factor(IluGeom G, const double *__re
         int l0;
         long c;
         k.ok = tile_cell(G, ti, s, l0, c);
-        k.has[0] = k.ok && l0 > 0; k.has[1] = k.ok && ti.j > 0; k.has[2] = k.ok && ti.k > 0;
-        k.hasu[0] = k.ok && l0 < ti.tt0 - 1; k.hasu[1] = k.ok && ti.j < ti.tj - 1; k.hasu[2] = k.ok && ti.k < ti.tk - 1;
+        const double2 *ch = reinterpret_cast<const double2 *>(Jt + ((long)tile * ns + s) * (L::PJ * 128)) + lane;
+        double v[2 * L::PJ];
+#pragma unroll
+        for (int p = 0; p < L::PJ; ++p) {
+            const double2 t = ch[p * 64];
+            v[2 * p] = t.x;
+            v[2 * p + 1] = t.y;
+        }
 #pragma unroll
         for (int r = 0; r < B; ++r)
 #pragma unroll
             for (int q = 0; q < B; ++q) {
-                k.D[r][q] = k.ok ? J[((long)(0 * B + r) * B + q) * nt + c] : 0.0;
+                k.D[r][q] = v[r * B + q];
 #pragma unroll
                 for (int a = 0; a < 3; ++a) {
-                    k.Acm[a][r][q] = k.has[a] ? J[((long)((1 + 2 * a) * B + r) * B + q) * nt + c] : 0.0;
-                    k.Aup[a][r][q] = k.hasu[a] ? J[((long)((2 + 2 * a) * B + r) * B + q) * nt + c] : 0.0;
+                    k.Acm[a][r][q] = v[((1 + 2 * a) * B + r) * B + q];
+                    k.Aup[a][r][q] = v[((2 + 2 * a) * B + r) * B + q];
                 }
             }
     };
@@ -176,7 +224,7 @@ __global__ __launch_bounds__(64) void k_ilu_factor(IluGeom G, const double *__re
                     double v = 0.0;
 #pragma unroll
                     for (int t = 0; t < B; ++t) v += k.Acm[a][r][t] * Dn[a][t][q];
-                    Bm[r][q] = k.has[a] ? v : 0.0;
+                    Bm[r][q] = v;                  // zero when the neighbour is outside the tile (A_cm = 0)
                 }
 #pragma unroll
             for (int r = 0; r < B; ++r)
@@ -210,7 +258,7 @@ __global__ __launch_bounds__(64) void k_ilu_factor(IluGeom G, const double *__re
 #pragma unroll
                     for (int t = 0; t < B; ++t) v += Di[r][t] * k.Aup[a][t][q];
                     const int e = (a * B + r) * B + q;
-                    bch[(e >> 1) * 128 + lane * 2 + (e & 1)] = k.hasu[a] ? v : 0.0;
+                    bch[(e >> 1) * 128 + lane * 2 + (e & 1)] = v;
                 }
 #pragma unroll
         for (int r = 0; r < B; ++r)
@@ -397,6 +445,7 @@ static void alloc_factor(IluData &d) {
     d.fwd.alloc(chunks * L::PF * 128);
     d.bwd.alloc(chunks * L::PB * 128);
     d.ytmp.alloc(chunks * L::PY * 128);
+    d.jt.alloc(chunks * L::PJ * 128);
 }
 
 void ilu_setup(tp_ctx *c) {
@@ -425,12 +474,18 @@ void ilu_factor(tp_ctx *c) {
     TP_REQUIRE(c->jac_ready, "Jacobian not assembled");
     if (c->ilu.slots == 0) ilu_setup(c);
     const IluGeom G = geom_of(c);
-    if (c->b == 3)
-        hipLaunchKernelGGL(k_ilu_factor<3>, dim3(c->ilu.ntiles), dim3(64), 0, c->stream, G, c->J.p, c->ilu.fwd.p,
+    const int nseg = (G.nsteps + ILU_SEG - 1) / ILU_SEG;
+    if (c->b == 3) {
+        hipLaunchKernelGGL(k_ilu_gather<3>, dim3(c->ilu.ntiles, (IluLayout<3>::PJ + ILU_PPT - 1) / ILU_PPT, nseg), dim3(64 * ILU_SEG), 0, c->stream, G,
+                           c->J.p, c->ilu.jt.p);
+        hipLaunchKernelGGL(k_ilu_factor<3>, dim3(c->ilu.ntiles), dim3(64), 0, c->stream, G, c->ilu.jt.p, c->ilu.fwd.p,
                            c->ilu.bwd.p);
-    else
-        hipLaunchKernelGGL(k_ilu_factor<2>, dim3(c->ilu.ntiles), dim3(64), 0, c->stream, G, c->J.p, c->ilu.fwd.p,
+    } else {
+        hipLaunchKernelGGL(k_ilu_gather<2>, dim3(c->ilu.ntiles, (IluLayout<2>::PJ + ILU_PPT - 1) / ILU_PPT, nseg), dim3(64 * ILU_SEG), 0, c->stream, G,
+                           c->J.p, c->ilu.jt.p);
+        hipLaunchKernelGGL(k_ilu_factor<2>, dim3(c->ilu.ntiles), dim3(64), 0, c->stream, G, c->ilu.jt.p, c->ilu.fwd.p,
                            c->ilu.bwd.p);
+    }
     TP_HIP(hipGetLastError());
 }
 
