@@ -133,8 +133,15 @@ void stage1_apply(tp_ctx *c, const double *x, double *y) {
     // y_s = 0 for the non-primary fields (:902-903, :1566-1567)
     const int npri = npri_of(c->opt);
     for (int f = npri; f < c->b; ++f) vec_zero(c, y + (long)f * nt, nt);
-    stage1_rhs(c, x, 0, r0);                       // r_p = x_p - (D_ps D_ss^-1) x_s
-    if (npri == 2) stage1_rhs(c, x, 1, r1);
+    if (c->opt.decoup == 0 && !c->dist) {
+        // decoupling "No" (pc_cptr, pc_cpr, pc_fieldsplit_cd presets): the stage-1 right-hand sides ARE the
+        // primary fields of x -- no copy (multi-GPU keeps the copy: the V-cycle's exchange writes b's halos)
+        r0 = const_cast<double *>(x);
+        r1 = const_cast<double *>(x) + nt;
+    } else {
+        stage1_rhs(c, x, 0, r0);                   // r_p = x_p - (D_ps D_ss^-1) x_s
+        if (npri == 2) stage1_rhs(c, x, 1, r1);
+    }
     if (c->dist && c->amg_p->dist_levels == 0) {
         // gathered global system: work vectors gr0, gr1, gy0, gy1, gt, gw on the global grid
         const GridDev &G = c->gfull;
