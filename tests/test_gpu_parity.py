@@ -41,6 +41,8 @@ CASES = [
     ("c4_2ph_3d_tiles", cases.c4_spe10_3d, dict(Nx=11, Ny=13, Nz=17, nphase=2), dict(pc="cptr", ilu_tile=(5, 4, 7))),
     ("c4_2ph_3d_fp32amg", cases.c4_spe10_3d, dict(Nx=9, Ny=14, Nz=8, nphase=2), dict(pc="cptr", amg_single=True)),
     ("c4_2ph_3d_v22", cases.c4_spe10_3d, dict(Nx=9, Ny=14, Nz=8, nphase=2), dict(pc="cptr", amg_full_levels=99)),
+    ("c4_2ph_3d_v02", cases.c4_spe10_3d, dict(Nx=9, Ny=14, Nz=8, nphase=2), dict(pc="cptr", amg_full_levels=2, amg_coarse_post=2)),
+    ("c4_2ph_3d_v11c", cases.c4_spe10_3d, dict(Nx=9, Ny=14, Nz=8, nphase=2), dict(pc="cptr", amg_full_levels=1, amg_coarse_pre=1, amg_coarse_post=1)),
     # single-phase block preconditioner pc_fieldsplit_cd (singlephase.py:309-319): ConvDiffSchurPC operator
     ("c4_1ph_3d_fscd", cases.c4_spe10_3d, dict(Nx=7, Ny=13, Nz=9, nphase=1), dict(pc="fieldsplit_cd")),
     ("c2_1ph_2d_fscd", cases.c3_spe10_2d, dict(Nx=14, Ny=19, nphase=1), dict(pc="fieldsplit_cd")),
