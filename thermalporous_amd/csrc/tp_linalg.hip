@@ -91,15 +91,27 @@ __global__ __launch_bounds__(256) void k_multi_dot(GridDev g, int nf, const doub
     }
 }
 
-__global__ __launch_bounds__(256) void k_reduce_partials(const double *partial, long nwaves, double *out) {
-    __shared__ double sh[4];
+// second stage of the deterministic two-stage sums: one workgroup per output.  Latency bound (a few thousand
+// partials): 1024 threads with 4 independent loads in flight each, fixed summation order.
+__global__ __launch_bounds__(1024) void k_reduce_partials(const double *__restrict__ partial, long nwaves,
+                                                          double *__restrict__ out) {
+    __shared__ double sh[16];
     const double *p = partial + (long)blockIdx.x * nwaves;
-    double s = 0.0;
-    for (long i = threadIdx.x; i < nwaves; i += 256) s += p[i];
-    s = wave_sum(s);
+    double s0 = 0.0, s1 = 0.0, s2 = 0.0, s3 = 0.0;
+    long i = threadIdx.x;
+    for (; i + 3 * 1024 < nwaves; i += 4 * 1024) {
+        s0 += p[i]; s1 += p[i + 1024]; s2 += p[i + 2 * 1024]; s3 += p[i + 3 * 1024];
+    }
+    for (; i < nwaves; i += 1024) s0 += p[i];
+    double s = wave_sum((s0 + s1) + (s2 + s3));
     if ((threadIdx.x & 63) == 0) sh[threadIdx.x >> 6] = s;
     __syncthreads();
-    if (threadIdx.x == 0) out[blockIdx.x] = sh[0] + sh[1] + sh[2] + sh[3];
+    if (threadIdx.x == 0) {
+        double t = 0.0;
+#pragma unroll
+        for (int w = 0; w < 16; ++w) t += sh[w];
+        out[blockIdx.x] = t;
+    }
 }
 
 static long md_nwaves(const tp_ctx *c, int nf) {
@@ -115,7 +127,7 @@ void multi_dot(tp_ctx *c, int nf, const double *V, long vstride, int k, const do
     if ((long)c->red_out.n < nout) c->red_out.alloc(nout + 64);
     hipLaunchKernelGGL(k_multi_dot, grid_for(nw * 64), dim3(256), 0, c->stream, c->g, nf, V, vstride, k, w, w2,
                        c->gs_partial.p, nw);
-    hipLaunchKernelGGL(k_reduce_partials, dim3(nout), dim3(256), 0, c->stream, c->gs_partial.p, nw, c->red_out.p);
+    hipLaunchKernelGGL(k_reduce_partials, dim3(nout), dim3(1024), 0, c->stream, c->gs_partial.p, nw, c->red_out.p);
     TP_HIP(hipGetLastError());
     allreduce_sum(c, c->red_out.p, nout);
     TP_HIP(hipMemcpyAsync(host_out, c->red_out.p, sizeof(double) * nout, hipMemcpyDeviceToHost, c->stream));
@@ -185,11 +197,11 @@ void orthogonalize(tp_ctx *c, int nf, const double *V, long vstride, int k, doub
     if ((long)c->red_out.n < k + 1) c->red_out.alloc(k + 65);
     hipLaunchKernelGGL(k_multi_dot, grid_for(nw * 64), dim3(256), 0, c->stream, c->g, nf, V, vstride, k, w,
                        (const double *)nullptr, c->gs_partial.p, nw);
-    hipLaunchKernelGGL(k_reduce_partials, dim3(k), dim3(256), 0, c->stream, c->gs_partial.p, nw, c->red_out.p);
+    hipLaunchKernelGGL(k_reduce_partials, dim3(k), dim3(1024), 0, c->stream, c->gs_partial.p, nw, c->red_out.p);
     allreduce_sum(c, c->red_out.p, k);
     hipLaunchKernelGGL(k_multi_axpy_norm, grid_for(nw * 64), dim3(256), 0, c->stream, c->g, nf, V, vstride, k,
                        c->red_out.p, w, c->gs_partial.p, nw);
-    hipLaunchKernelGGL(k_reduce_partials, dim3(1), dim3(256), 0, c->stream, c->gs_partial.p, nw, c->red_out.p + k);
+    hipLaunchKernelGGL(k_reduce_partials, dim3(1), dim3(1024), 0, c->stream, c->gs_partial.p, nw, c->red_out.p + k);
     TP_HIP(hipGetLastError());
     allreduce_sum(c, c->red_out.p + k, 1);
     TP_HIP(hipMemcpyAsync(host_out, c->red_out.p, sizeof(double) * (k + 1), hipMemcpyDeviceToHost, c->stream));
