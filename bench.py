@@ -129,7 +129,14 @@ def main():
     bpc = SPMV_BYTES_PER_CELL[(eng.b, 7 if eng.gn[2] > 1 else 5)]
     achieved = bpc*ncell_local/(ms*1e-3)/1e9
     extra = {nm: eng.time_kernel(w, 20) for w, nm in ((1, "ilu_solve_ms"), (2, "amg_vcycle_ms"), (3, "assembly_ms"),
-                                                       (4, "pc_apply_ms"))}
+                                                       (4, "pc_apply_ms"), (5, "pc_setup_ms"), (6, "ilu_factor_ms"))}
+    # the other streaming kernels against the same roofline (algorithmic bytes per cell: SURVEY.md 8d)
+    others = {}
+    if eng.b == 3 and eng.gn[2] > 1:
+        for nm, key, bytes_per_cell in (("ilu0_solve", "ilu_solve_ms", 584), ("assembly_residual_jacobian", "assembly_ms", 616),
+                                        ("ilu0_factor(gather+factor)", "ilu_factor_ms", 1040)):
+            gbs = bytes_per_cell*ncell_local/(extra[key]*1e-3)/1e9
+            others[nm] = {"bytes_per_cell": bytes_per_cell, "avg_ms": extra[key], "achieved_GBs": gbs, "frac": gbs/HBM_PEAK_GBS}
     if rank != 0:
         return
     # HBM traffic per launch of the same kernel from the PMC passes (rocprofv3 --pmc FETCH_SIZE / WRITE_SIZE in
@@ -167,7 +174,7 @@ def main():
         "roofline": {"bound": "hbm", "achieved": achieved, "peak": HBM_PEAK_GBS, "unit": "GB/s",
                      "frac": achieved/HBM_PEAK_GBS, "traffic": traffic,
                      "kernel": "k_spmv_block<3,7,3,0>", "bytes_per_cell": bpc, "cells_per_launch": ncell_local,
-                     "avg_ms": ms},
+                     "avg_ms": ms, "other_kernels": others},
     }
     if not args.no_cpu_baseline and world == 1:
         out["cpu_baseline"] = cpu_baseline()
