@@ -141,6 +141,16 @@ def test_solver_option_mapping_and_rejections():
         SinglePhase(g, c, p, solver_parameters="pc_fieldsplit_selfp", filename=None, _engine_factory=OracleEngine)
     with pytest.raises(NotImplementedError):
         TwoPhase(g, c, p2, solver_parameters="pc_cptramg_QI", filename=None, _engine_factory=OracleEngine)
+    # the pure-PETSc "*_gmres" emulations (twophase.py:619-699, singlephase.py:355-368) are the same algebra
+    c2 = WellCase(p2, g, well_case="test0", constant_rate=True)
+    m4 = TwoPhase(g, c2, p2, filename=None, verbosity=False, _engine_factory=OracleEngine)      # default preset (:930)
+    assert m4.engine_opts["pc"] == "cptr" and m4.engine_opts["decoup"] == "No"
+    m5 = TwoPhase(g, c2, p2, solver_parameters="pc_cpr_gmres", filename=None, verbosity=False, _engine_factory=OracleEngine)
+    assert m5.engine_opts["pc"] == "cpr" and m5.engine_opts["decoup"] == "No"
+    m6 = SinglePhase(g, c, p, solver_parameters="pc_cpr_gmres", filename=None, verbosity=False, _engine_factory=OracleEngine)
+    assert m6.engine_opts["pc"] == "cpr"
+    with pytest.raises(NotImplementedError):     # ILU(1) second stage
+        engine_options({**m5.solver_parameters, "sub_1_sub_pc_factor_levels": 1}, "Two-phase")
     with pytest.raises(NotImplementedError):
         engine_options({"pc_type": "lu", "ksp_type": "preonly"}, "Single phase")
     with pytest.raises(KeyError):

@@ -78,7 +78,16 @@ class SinglePhase(ThermalModel):
         presets = {"pc_cpr": pc_cpr,
                    "pc_cpr_QI": {**pc_cpr, "sub_0_cpr_decoup": "QI"},      # (:353)
                    "pc_cpr_TI": {**pc_cpr, "sub_0_cpr_decoup": "TI"},      # (:354)
-                   "pc_fieldsplit_cd": pc_fieldsplit_cd}
+                   "pc_fieldsplit_cd": pc_fieldsplit_cd,
+                   "pc_cpr_gmres": {"pc_type": "composite",        # (:355-368) pure-PETSc emulation of pc_cpr
+                                    "pc_composite_type": "multiplicative",
+                                    "pc_composite_pcs": "fieldsplit,bjacobi",
+                                    "sub_0_pc_fieldsplit_type": "additive",
+                                    "sub_0_fieldsplit_0": v_cycle,
+                                    "sub_0_fieldsplit_1": {"ksp_type": "gmres", "ksp_max_it": 0, "pc_type": "none"},
+                                    "sub_1_sub_pc_type": "ilu",
+                                    "sub_1_sub_pc_factor_levels": 0,
+                                    "mat_type": "aij"}}
         parameters = newton
         if self.solver_parameters is None:
             # the reference's default name "pc_fieldsplit" matches no branch (:410-439) and silently runs

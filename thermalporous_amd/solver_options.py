@@ -72,6 +72,37 @@ def engine_options(solver_parameters, model_name, decoup="No"):
             if not (k in _IGNORED or k.startswith(("fieldsplit_", "pc_", "ksp_", "snes_"))):
                 raise KeyError("unknown solver parameter %r" % k)
         return o
+    if sp.get("pc_type") == "composite" and sp.get("pc_composite_pcs") == "fieldsplit,bjacobi":
+        # the reference's pure-PETSc emulations of its python stage-1 classes (singlephase.py:355-368,
+        # twophase.py:619-634,670-699): additive fieldsplit whose second split is "gmres, max_it 0, pc none" -- i.e.
+        # returns zero, exactly the y_nonp = 0 of CPRStage1PC/CPTRStage1PC.apply -- with decoupling "No".
+        # pc_cpr_gmres == pc_cpr and pc_cptr_gmres == pc_cptr (the two-phase default, twophase.py:930) as algebra.
+        if sp.get("pc_composite_type", "multiplicative") != "multiplicative" or sp.get("sub_0_pc_fieldsplit_type") != "additive" \
+                or sp.get("sub_0_fieldsplit_1_ksp_type") != "gmres" or int(sp.get("sub_0_fieldsplit_1_ksp_max_it", -1)) != 0 \
+                or sp.get("sub_0_fieldsplit_1_pc_type") != "none":
+            raise NotImplementedError("fieldsplit,bjacobi composite: only the *_gmres emulations of pc_cpr / pc_cptr")
+        if sp.get("sub_1_sub_pc_type", "ilu") != "ilu" or int(sp.get("sub_1_sub_pc_factor_levels", 0)) != 0:
+            raise NotImplementedError("stage 2 must be ILU(0) (pc_cprilu1_gmres is not on the hot path)")
+        if o["decoup"] != "No":
+            raise NotImplementedError("the fieldsplit emulations have no decoupling stage")
+        if sp.get("sub_0_fieldsplit_0_pc_type") == "hypre":
+            if sp.get("sub_0_pc_fieldsplit_0_fields", "0") != "0":
+                raise NotImplementedError("system AMG on several fields (pc_cptramg_gmres) is not on the hot path")
+            o["pc"] = "cpr"
+        elif sp.get("sub_0_fieldsplit_0_pc_type") == "fieldsplit" \
+                and sp.get("sub_0_fieldsplit_0_pc_fieldsplit_type") == "schur" \
+                and str(sp.get("sub_0_fieldsplit_0_pc_fieldsplit_schur_fact_type", "")).upper() == "FULL" \
+                and str(sp.get("sub_0_fieldsplit_0_fieldsplit_1_pc_python_type", "")).endswith("ConvDiffSchurTwoPhasesPC"):
+            if model_name != "Two-phase":
+                raise NotImplementedError("pc_cptr_gmres needs the two-phase model")
+            o["pc"] = "cptr"
+        else:
+            raise NotImplementedError("unsupported first split of the fieldsplit,bjacobi composite "
+                                      "(mg/LU/system-AMG variants are not on the hot path)")
+        for k in sp:
+            if not (k in _IGNORED or k.startswith(("sub_0_", "sub_1_", "pc_", "ksp_", "snes_"))):
+                raise KeyError("unknown solver parameter %r" % k)
+        return o
     if sp.get("pc_type") != "composite" or sp.get("pc_composite_type", "multiplicative") != "multiplicative" \
             or sp.get("pc_composite_pcs") != "python,bjacobi":
         raise NotImplementedError(

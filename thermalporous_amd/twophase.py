@@ -89,13 +89,44 @@ class TwoPhase(ThermalModel):
                   "sub_1_sub_pc_type": "ilu",
                   "sub_1_sub_pc_factor_levels": 0,
                   "mat_type": "aij"}
+        gmres0 = {"ksp_type": "gmres", "ksp_max_it": 0, "pc_type": "none"}     # "apply nothing": returns zero
+        pc_cpr_gmres = {"pc_type": "composite",       # (:619-634) pure-PETSc emulation of pc_cpr
+                        "pc_composite_type": "multiplicative",
+                        "pc_composite_pcs": "fieldsplit,bjacobi",
+                        "sub_0_pc_fieldsplit_0_fields": "0",
+                        "sub_0_pc_fieldsplit_1_fields": "1,2",
+                        "sub_0_pc_fieldsplit_type": "additive",
+                        "sub_0_fieldsplit_0": v_cycle,
+                        "sub_0_fieldsplit_1": gmres0,
+                        "sub_1_sub_pc_type": "ilu",
+                        "sub_1_sub_pc_factor_levels": 0,
+                        "mat_type": "aij"}
+        pc_cptr_gmres = {"pc_type": "composite",      # (:670-699) pure-PETSc emulation of pc_cptr; the default (:930)
+                         "pc_composite_type": "multiplicative",
+                         "pc_composite_pcs": "fieldsplit,bjacobi",
+                         "sub_0_pc_fieldsplit_0_fields": "0,1",
+                         "sub_0_pc_fieldsplit_1_fields": "2",
+                         "sub_0_pc_fieldsplit_type": "additive",
+                         "sub_0_fieldsplit_0_pc_type": "fieldsplit",
+                         "sub_0_fieldsplit_0_pc_fieldsplit_type": "schur",
+                         "sub_0_fieldsplit_0_pc_fieldsplit_schur_fact_type": "FULL",
+                         "sub_0_fieldsplit_0_fieldsplit_1_ksp_type": "preonly",
+                         "sub_0_fieldsplit_0_fieldsplit_1_pc_type": "python",
+                         "sub_0_fieldsplit_0_fieldsplit_1_pc_python_type":
+                             "thermalporous.preconditioners.ConvDiffSchurTwoPhasesPC",
+                         "sub_0_fieldsplit_0_fieldsplit_1_schur": v_cycle,
+                         "sub_0_fieldsplit_0_fieldsplit_0": v_cycle,
+                         "sub_0_fieldsplit_1": gmres0,
+                         "sub_1_sub_pc_type": "ilu",
+                         "sub_1_sub_pc_factor_levels": 0,
+                         "mat_type": "aij"}
         presets = {"pc_cptr": pc_cptr, "pc_cpr": pc_cpr,
                    "pc_cpr_QI": {**pc_cpr, "sub_0_cpr_decoup": "QI"},      # (:594)
-                   "pc_cpr_TI": {**pc_cpr, "sub_0_cpr_decoup": "TI"}}      # (:595)
+                   "pc_cpr_TI": {**pc_cpr, "sub_0_cpr_decoup": "TI"},      # (:595)
+                   "pc_cpr_gmres": pc_cpr_gmres, "pc_cptr_gmres": pc_cptr_gmres}
         parameters = newton_krylov
         if self.solver_parameters is None:
-            # reference default "pc_cptr_gmres" (:930) is the fieldsplit emulation of pc_cptr
-            self.solver_parameters = "pc_cptr"
+            self.solver_parameters = "pc_cptr_gmres"       # the reference's default (:930); same algebra as pc_cptr
         if isinstance(self.solver_parameters, str):
             if self.solver_parameters not in presets:
                 raise NotImplementedError("two-phase preset %r is outside the hot path; available: %s"
