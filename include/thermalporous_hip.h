@@ -67,7 +67,8 @@ typedef struct tp_options {
                                 with fieldsplit Schur FULL, V(App), V(S~)), 2 = pc_fieldsplit_cd
                                 (single-phase: fieldsplit Schur FULL on (p,T) with V(App) and the
                                 ConvDiffSchurPC V(S~), no second stage; singlephase.py:309-319) */
-    int32_t decoup;          /* 0 "No", 1 "QI", 2 "TI"  (option key sub_0_cpr_decoup) */
+    int32_t decoup;          /* 0 "No", 1 "QI", 2 "TI", 3 "QI_temp", 4 "TI_temp" (option key sub_0_cpr_decoup;
+                                the _temp variants decouple both T and S: two-phase pc_cpr only) */
     double  ksp_rtol, ksp_atol;
     int32_t ksp_max_it, ksp_restart;
     double  snes_rtol, snes_atol, snes_stol;

@@ -338,6 +338,8 @@ def decouple(J, kind, primary):
     shape = J.shape[3:]
     if kind == "No":
         return J[:, primary][:, :, primary].copy(), None
+    if kind in ("QI_temp", "TI_temp"):
+        return _decouple_temp(J, kind, primary)
     if kind == "QI":
         Dss = J[0, s, s]
         D0s = [J[0, q, s] for q in primary]
@@ -364,6 +366,36 @@ def decouple(J, kind, primary):
         for j, c in enumerate(primary):
             At[:, i, j] = J[:, q, c] - d[i][None] * J[:, s, c]
     return At, d
+
+
+def _decouple_temp(J, kind, primary):
+    """QI_temp / TI_temp (preconditioners.py:714-783, 810-873): two-phase CPR where BOTH non-pressure fields
+    (T, S) are decoupled: per cell D_ss is the 2x2 block [[D_TT, D_TS], [D_ST, D_SS]] and D_ps = [D_pT, D_pS]
+    (diagonal entries for QI_temp, column sums for TI_temp);  Atilde_pp = A_pp - D_ps D_ss^-1 A_sp  and
+    r_p = x_p - D_ps D_ss^-1 x_s.  Returns (Atilde [7,1,1,...], d) with d[0] = (d_T, d_S) per cell."""
+    assert J.shape[1] == 3 and list(primary) == [0], "the _temp decouplings are two-phase pressure-only variants"
+    shape = J.shape[3:]
+
+    def entry(q, c):
+        if kind == "QI_temp":
+            return J[0, q, c]
+        AT = J[:, q, c]
+        out = AT[0].copy()
+        for a in range(3):
+            if shape[2 - a] == 1:
+                continue
+            lo, hi = _lo(a), _hi(a)
+            out[hi] += AT[2 + 2 * a][lo]
+            out[lo] += AT[1 + 2 * a][hi]
+        return out
+    DTT, DTS, DST, DSS = entry(1, 1), entry(1, 2), entry(2, 1), entry(2, 2)
+    DpT, DpS = entry(0, 1), entry(0, 2)
+    det = DTT * DSS - DTS * DST
+    dT = (DpT * DSS - DpS * DST) / det          # [DpT DpS] . inv([[DTT DTS],[DST DSS]])
+    dS = (DpS * DTT - DpT * DTS) / det
+    At = np.zeros((7, 1, 1) + shape)
+    At[:, 0, 0] = J[:, 0, 0] - dT[None] * J[:, 1, 0] - dS[None] * J[:, 2, 0]
+    return At, [(dT, dS)]
 
 
 def slab_ranges(n2, nslabs):
@@ -429,7 +461,12 @@ class TwoStagePC:
         o = self.o
         s = x.shape[0] - 1
         if o["pc"] == "cpr":
-            r = x[0] if self.d is None else x[0] - self.d[0] * x[s]
+            if self.d is None:
+                r = x[0]
+            elif o["decoup"] in ("QI_temp", "TI_temp"):
+                r = x[0] - self.d[0][0] * x[1] - self.d[0][1] * x[2]
+            else:
+                r = x[0] - self.d[0] * x[s]
             y[0] = self.amg_p.vcycle(r)
             self.vcycles += 1
         else:

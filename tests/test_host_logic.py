@@ -285,8 +285,14 @@ def test_pc_classes_mirror_pcbase_protocol():
     assert e.opts == {"pc": "cptr", "decoup": "QI"}
     assert e.calls.count("pc_setup") == 2 and e.calls[-1] == ("stage1_apply", "x", "y")
     assert pc.getOptionsPrefix() == "sub_0_"
+    e.b = 2                                        # single-phase engine: the _temp decouplings need (T, S)
     with pytest.raises(NotImplementedError):
         pcs.CPRStage1PC().setUp(pcs.PC(e, {"decoup": "QI_temp"}))
+    with pytest.raises(NotImplementedError):
+        pcs.CPRStage1PC().setUp(pcs.PC(e, {"decoup": "bogus"}))
+    e.b = 3
+    pcs.CPRStage1PC().setUp(pcs.PC(e, {"decoup": "TI_temp"}))
+    assert e.opts["decoup"] == "TI_temp"
 
 
 def test_convergence_error_is_raised_like_firedrake():

@@ -65,6 +65,34 @@ def test_cpr_decoupling_matches_petsc_algebra(kind, nphase):
     assert np.allclose((x[0] - d[0]*x[s]).reshape(-1), r_ref, rtol=1e-12 if kind == "QI" else 1e-5)
 
 
+@pytest.mark.parametrize("kind", ["QI_temp", "TI_temp"])
+def test_cpr_temp_decoupling_matches_petsc_algebra(kind):
+    """QI_temp / TI_temp (preconditioners.py:714-783, 810-873): per cell invDss = inverse of the 2x2 block
+    [[TT, TS], [ST, SS]] of diagonals / column sums, Dps = [pT, pS]; Atildepp = App - Dps invDss Asp with
+    s = (T,S).  Written with scipy matrices in the reference's order of operations."""
+    spec, o = setup_case(Nx=5, Ny=6, Nz=4, nphase=2, opts=dict(pc="cpr", decoup=kind))
+    J = o.jacobian()
+    A = _field_major_blocks(J)
+    n = A[0][0].shape[0]
+
+    def vec(M):
+        return M.diagonal() if kind == "QI_temp" else np.asarray(M.T.sum(axis=1)).ravel()
+    blk = np.empty((n, 2, 2))
+    blk[:, 0, 0], blk[:, 0, 1], blk[:, 1, 0], blk[:, 1, 1] = vec(A[1][1]), vec(A[1][2]), vec(A[2][1]), vec(A[2][2])
+    inv = np.linalg.inv(blk)                                         # the per-cell np.linalg.inv(block) loop (:746-755)
+    invDss = sp.bmat([[sp.diags(inv[:, 0, 0]), sp.diags(inv[:, 0, 1])], [sp.diags(inv[:, 1, 0]), sp.diags(inv[:, 1, 1])]])
+    Dps = sp.hstack([sp.diags(vec(A[0][1])), sp.diags(vec(A[0][2]))])
+    Asp = sp.vstack([A[1][0], A[2][0]])
+    apsinvdss = Dps @ invDss
+    Atilde = A[0][0] - apsinvdss @ Asp
+    At, d = la.decouple(J, kind, [0])
+    tol = 1e-12 if kind == "QI_temp" else 1e-6                       # TI column sums cancel (see above)
+    assert abs(la.to_csr(At) - Atilde).max() < tol*abs(Atilde).max()
+    x = np.random.default_rng(1).standard_normal(J.shape[1:2] + J.shape[3:])
+    r_ref = x[0].reshape(-1) - apsinvdss @ np.concatenate([x[1].reshape(-1), x[2].reshape(-1)])     # :889-895
+    assert np.allclose((x[0] - d[0][0]*x[1] - d[0][1]*x[2]).reshape(-1), r_ref, rtol=1e-12 if kind == "QI_temp" else 1e-5)
+
+
 @pytest.mark.parametrize("kind", ["QI", "TI"])
 def test_cptr_decoupling_matches_petsc_algebra(kind):
     """Atilde00 = A00 - D0s Dss^-1 As0, primary = (p,T) (preconditioners.py:1445-1543)."""

@@ -371,6 +371,38 @@ __global__ void k_decoup_apply(GridDev g, const double *J, int npri, const doubl
         }
 }
 
+// QI_temp / TI_temp (preconditioners.py:714-783, 810-873): two-phase pressure-only CPR where both non-pressure
+// fields are decoupled -- D_ss is a 2x2 block per cell:  (d_T, d_S) = [D_pT D_pS] inv([[D_TT D_TS],[D_ST D_SS]]),
+// Atilde_pp = A_pp - d_T A_Tp - d_S A_Sp,  r_p = x_p - d_T x_T - d_S x_S.
+__global__ void k_decoup_temp(GridDev g, const double *J, int ti, double *d, double *At) {
+    const long tid = (long)blockIdx.x * blockDim.x + threadIdx.x;
+    if (tid >= g.nown) return;
+    const long c = g.np + tid, nt = g.ntot;
+    constexpr int B = 3;
+    const long off[7] = {0, -1, 1, -(long)g.n0, (long)g.n0, -g.np, g.np};
+    auto entry = [&](int q, int s) {
+        double v = J[((long)(0 * B + q) * B + s) * nt + c];
+        if (ti) {
+#pragma unroll
+            for (int a = 0; a < 3; ++a) {
+                v += J[((long)((2 + 2 * a) * B + q) * B + s) * nt + c + off[1 + 2 * a]];   // row c-a, slot +a
+                v += J[((long)((1 + 2 * a) * B + q) * B + s) * nt + c + off[2 + 2 * a]];   // row c+a, slot -a
+            }
+        }
+        return v;
+    };
+    const double DTT = entry(1, 1), DTS = entry(1, 2), DST = entry(2, 1), DSS = entry(2, 2);
+    const double DpT = entry(0, 1), DpS = entry(0, 2);
+    const double det = DTT * DSS - DTS * DST;
+    const double dT = (DpT * DSS - DpS * DST) / det, dS = (DpS * DTT - DpT * DTS) / det;
+    d[c] = dT;
+    d[nt + c] = dS;
+#pragma unroll
+    for (int slot = 0; slot < 7; ++slot)
+        At[(long)slot * nt + c] = J[((long)(slot * B + 0) * B + 0) * nt + c] - dT * J[((long)(slot * B + 1) * B + 0) * nt + c] -
+                                  dS * J[((long)(slot * B + 2) * B + 0) * nt + c];
+}
+
 void decouple(tp_ctx *c) {
     const GridDev &g = c->g;
     const int npri = npri_of(c->opt);
@@ -381,6 +413,18 @@ void decouple(tp_ctx *c) {
         c->opA00.base = c->J.p;                                  c->opA00.slot_stride = (long)B * B * nt;
         c->opA01.base = c->J.p + 1 * nt;                         c->opA01.slot_stride = (long)B * B * nt;
         c->opA10.base = c->J.p + (long)B * nt;                   c->opA10.slot_stride = (long)B * B * nt;
+        return;
+    }
+    if (c->opt.decoup >= 3) {       // QI_temp (3) / TI_temp (4)
+        TP_REQUIRE(B == 3 && c->opt.pc_kind == 0, "QI_temp/TI_temp are two-phase pc_cpr decouplings");
+        if (c->At.n < (size_t)7 * nt) c->At.alloc((size_t)7 * nt);
+        if (c->dcoef.n < (size_t)2 * nt) c->dcoef.alloc((size_t)2 * nt);
+        const int tit = c->opt.decoup == 4;
+        if (tit && c->dist) halo_exchange(c, g, c->J.p, 7 * B * B, nt);
+        hipLaunchKernelGGL(k_decoup_temp, grid_for(g.nown), dim3(256), 0, c->stream, g, c->J.p, tit, c->dcoef.p, c->At.p);
+        TP_HIP(hipGetLastError());
+        c->opA00.base = c->At.p; c->opA00.slot_stride = nt;
+        c->opA01 = c->opA00; c->opA10 = c->opA00;      // unused for pc_cpr
         return;
     }
     if (c->At.n < (size_t)7 * npri * npri * nt) c->At.alloc((size_t)7 * npri * npri * nt);
@@ -409,8 +453,20 @@ __global__ void k_stage1_rhs(GridDev g, const double *x, const double *d, int q,
     const long c = g.np + tid, nt = g.ntot;
     out[c] = d ? x[(long)q * nt + c] - d[(long)q * nt + c] * x[(long)s * nt + c] : x[(long)q * nt + c];
 }
+// _temp variants: out = x_p - d_T x_T - d_S x_S
+__global__ void k_stage1_rhs_temp(GridDev g, const double *x, const double *d, double *out) {
+    const long tid = (long)blockIdx.x * blockDim.x + threadIdx.x;
+    if (tid >= g.nown) return;
+    const long c = g.np + tid, nt = g.ntot;
+    out[c] = x[c] - d[c] * x[nt + c] - d[nt + c] * x[2 * nt + c];
+}
 
 void stage1_rhs(tp_ctx *c, const double *x, int q, double *out) {
+    if (c->opt.decoup >= 3) {
+        hipLaunchKernelGGL(k_stage1_rhs_temp, grid_for(c->g.nown), dim3(256), 0, c->stream, c->g, x, c->dcoef.p, out);
+        TP_HIP(hipGetLastError());
+        return;
+    }
     const double *d = c->opt.decoup == 0 ? nullptr : c->dcoef.p;
     hipLaunchKernelGGL(k_stage1_rhs, grid_for(c->g.nown), dim3(256), 0, c->stream, c->g, x, d, q, c->b - 1, out);
     TP_HIP(hipGetLastError());

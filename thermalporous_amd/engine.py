@@ -75,7 +75,7 @@ DEFAULT_OPTS = dict(
 )
 
 _PC = {"cpr": 0, "cptr": 1, "fieldsplit_cd": 2}
-_DECOUP = {"No": 0, "QI": 1, "TI": 2}
+_DECOUP = {"No": 0, "QI": 1, "TI": 2, "QI_temp": 3, "TI_temp": 4}
 
 
 def load_library(path=None):

@@ -66,9 +66,10 @@ class CPRStage1PC(PCBase):
     def initialize(self, pc):
         appctx = self.get_appctx(pc)
         self.decoup = appctx["decoup"]                 # (:370)
-        if self.decoup not in ("No", "QI", "TI"):
-            raise NotImplementedError("decoupling %r: QI_temp/TI_temp are experimental variants outside the "
-                                      "hot path" % self.decoup)
+        if self.decoup not in ("No", "QI", "TI", "QI_temp", "TI_temp"):
+            raise NotImplementedError("unknown decoupling %r" % self.decoup)
+        if self.decoup.endswith("_temp") and (self.kind != "cpr" or pc.engine.b != 3):
+            raise NotImplementedError("QI_temp/TI_temp: two-phase CPRStage1PC only (:367-368)")
         eng = pc.engine
         if eng.opts["pc"] != self.kind or eng.opts["decoup"] != self.decoup:
             eng.set_options(pc=self.kind, decoup=self.decoup)

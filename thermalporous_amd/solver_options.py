@@ -120,8 +120,11 @@ def engine_options(solver_parameters, model_name, decoup="No"):
                                       "pc_cptr; system-AMG/LU variants (pc_cptramg*, pc_cptrlu*) are not")
     else:
         raise NotImplementedError("sub_0_pc_python_type %r" % pytype)
-    if o["decoup"] not in ("No", "QI", "TI"):
-        raise NotImplementedError("decoupling %r (QI_temp/TI_temp are experimental variants)" % o["decoup"])
+    if o["decoup"] not in ("No", "QI", "TI", "QI_temp", "TI_temp"):
+        raise NotImplementedError("unknown decoupling %r" % o["decoup"])
+    if o["decoup"].endswith("_temp") and (o["pc"] != "cpr" or model_name != "Two-phase"):
+        raise NotImplementedError("QI_temp/TI_temp decouple temperature AND saturation from the pressure: "
+                                  "two-phase pc_cpr only (preconditioners.py:367-368)")
     if sp.get("sub_1_sub_pc_type", "ilu") != "ilu" or int(sp.get("sub_1_sub_pc_factor_levels", 0)) != 0:
         raise NotImplementedError("stage 2 must be ILU(0)")
     known_prefixes = ("sub_0_", "sub_1_", "pc_", "ksp_", "snes_")

@@ -123,6 +123,8 @@ class TwoPhase(ThermalModel):
         presets = {"pc_cptr": pc_cptr, "pc_cpr": pc_cpr,
                    "pc_cpr_QI": {**pc_cpr, "sub_0_cpr_decoup": "QI"},      # (:594)
                    "pc_cpr_TI": {**pc_cpr, "sub_0_cpr_decoup": "TI"},      # (:595)
+                   "pc_cpr_QI_temp": {**pc_cpr, "sub_0_cpr_decoup": "QI_temp"},      # (:596)
+                   "pc_cpr_TI_temp": {**pc_cpr, "sub_0_cpr_decoup": "TI_temp"},      # (:597)
                    "pc_cpr_gmres": pc_cpr_gmres, "pc_cptr_gmres": pc_cptr_gmres}
         parameters = newton_krylov
         if self.solver_parameters is None:
