@@ -81,6 +81,9 @@ typedef struct tp_options {
     int32_t amg_full_levels; /* V(nu,nu) on the first amg_full_levels levels ... */
     int32_t amg_coarse_pre, amg_coarse_post;  /* ... V(coarse_pre, coarse_post) below (coarse_post >= 1) */
     int32_t amg_single;      /* 1: AMG operators/weights stored in fp32 (vectors and arithmetic stay fp64) */
+    int32_t schur_a11;       /* pc_kind 1/2: precondition the Schur complement with A_11 (the T-T block, after
+                                decoupling) instead of the convection-diffusion operator S~
+                                (pc_fieldsplit_schur_precondition a11: pc_fieldsplit_a11, pc_cptr_a11) */
     int32_t amg_gather_cells;/* multi-GPU: AMG levels with more cells than this stay distributed over the slabs
                                 (halo exchange per sweep); smaller ones are gathered and replicated on every
                                 rank.  < 0: replicate the whole hierarchy.  Ignored on one GPU. */

@@ -445,14 +445,15 @@ class TwoStagePC:
             At, self.d = decouple(J, o["decoup"], [0, 1])
             self.At = At
             self.amg_p.setup(At[:, 0, 0])
-            self.amg_T.setup(Sm)
+            # K(S): the convection-diffusion operator S~, or (schur_precondition a11, twophase.py:598-616) A_11
+            self.amg_T.setup(At[:, 1, 1] if o.get("schur_a11") else Sm)
         elif o["pc"] == "fieldsplit_cd":
             # single-phase block preconditioner (singlephase.py:309-319): the same Schur FULL stage on the
             # undecoupled (p,T) system with the ConvDiffSchurPC operator (preconditioners.py:11-163); no stage 2
             assert J.shape[1] == 2 and o["decoup"] == "No"
             self.At, self.d = decouple(J, "No", [0, 1])
             self.amg_p.setup(self.At[:, 0, 0])
-            self.amg_T.setup(Sm)
+            self.amg_T.setup(self.At[:, 1, 1] if o.get("schur_a11") else Sm)     # (singlephase.py:331-338: a11)
         else:
             raise ValueError(o["pc"])
 

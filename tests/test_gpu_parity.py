@@ -46,6 +46,10 @@ CASES = [
     # QI_temp / TI_temp: temperature AND saturation decoupled from the pressure (preconditioners.py:714-783, 810-873)
     ("c4_2ph_3d_cprQItemp", cases.c4_spe10_3d, dict(Nx=9, Ny=10, Nz=5, nphase=2), dict(pc="cpr", decoup="QI_temp")),
     ("c4_2ph_3d_cprTItemp", cases.c4_spe10_3d, dict(Nx=7, Ny=8, Nz=6, nphase=2), dict(pc="cpr", decoup="TI_temp")),
+    # Schur complement preconditioned by A_11 instead of S~ (pc_cptr_a11 twophase.py:598-616, pc_fieldsplit_a11)
+    ("c4_2ph_3d_cptr_a11", cases.c4_spe10_3d, dict(Nx=7, Ny=8, Nz=6, nphase=2), dict(pc="cptr", schur_a11=True)),
+    ("c4_2ph_3d_cptrQI_a11", cases.c4_spe10_3d, dict(Nx=7, Ny=8, Nz=6, nphase=2), dict(pc="cptr", decoup="QI", schur_a11=True)),
+    ("c4_1ph_3d_fs_a11", cases.c4_spe10_3d, dict(Nx=7, Ny=8, Nz=6, nphase=1), dict(pc="fieldsplit_cd", schur_a11=True)),
     # single-phase block preconditioner pc_fieldsplit_cd (singlephase.py:309-319): ConvDiffSchurPC operator
     ("c4_1ph_3d_fscd", cases.c4_spe10_3d, dict(Nx=7, Ny=13, Nz=9, nphase=1), dict(pc="fieldsplit_cd")),
     ("c2_1ph_2d_fscd", cases.c3_spe10_2d, dict(Nx=14, Ny=19, nphase=1), dict(pc="fieldsplit_cd")),

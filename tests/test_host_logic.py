@@ -139,6 +139,11 @@ def test_solver_option_mapping_and_rejections():
         engine_options(m3.solver_parameters, "Two-phase")
     with pytest.raises(NotImplementedError):
         SinglePhase(g, c, p, solver_parameters="pc_fieldsplit_selfp", filename=None, _engine_factory=OracleEngine)
+    m7 = SinglePhase(g, c, p, solver_parameters="pc_fieldsplit_a11", filename=None, verbosity=False, _engine_factory=OracleEngine)
+    assert m7.engine_opts["pc"] == "fieldsplit_cd" and m7.engine_opts["schur_a11"] is True and m3.engine_opts["schur_a11"] is False
+    m8 = TwoPhase(g, WellCase(p2, g, well_case="test0", constant_rate=True), p2, solver_parameters="pc_cptr_a11", filename=None,
+                  verbosity=False, _engine_factory=OracleEngine)
+    assert m8.engine_opts["pc"] == "cptr" and m8.engine_opts["schur_a11"] is True and m2.engine_opts["schur_a11"] is False
     with pytest.raises(NotImplementedError):
         TwoPhase(g, c, p2, solver_parameters="pc_cptramg_QI", filename=None, _engine_factory=OracleEngine)
     # the pure-PETSc "*_gmres" emulations (twophase.py:619-699, singlephase.py:355-368) are the same algebra

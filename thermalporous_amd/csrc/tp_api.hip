@@ -297,7 +297,8 @@ int tp_set_options(tp_ctx *c, const tp_options *opt) {
     TP_REQUIRE(c && opt, "null argument");
     const bool tile_changed = opt->ilu_t1 != c->opt.ilu_t1 || opt->ilu_t2 != c->opt.ilu_t2 || opt->ilu_t0 != c->opt.ilu_t0;
     const bool amg_changed = opt->amg_min_cells != c->opt.amg_min_cells || opt->pc_kind != c->opt.pc_kind ||
-                             opt->amg_single != c->opt.amg_single || opt->amg_gather_cells != c->opt.amg_gather_cells;
+                             opt->amg_single != c->opt.amg_single || opt->amg_gather_cells != c->opt.amg_gather_cells ||
+                             opt->schur_a11 != c->opt.schur_a11;
     c->opt = *opt;
     if (tile_changed) c->ilu.slots = 0;
     if (amg_changed) { delete c->amg_p; c->amg_p = nullptr; delete c->amg_T; c->amg_T = nullptr; }

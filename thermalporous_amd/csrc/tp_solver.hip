@@ -85,7 +85,14 @@ void pc_setup(tp_ctx *c) {
     Stencil Sl;
     Sl.base = c->Sm.p;
     Sl.slot_stride = c->g.ntot;
-    if (cptr) TP_REQUIRE(c->Sm.p, "pc_cptr needs the S~ operator (assemble with want_schur)");
+    if (cptr && c->opt.schur_a11) {
+        // pc_fieldsplit_schur_precondition a11 (singlephase.py:331-338, twophase.py:598-616): the T-T block of the
+        // (decoupled) primary system stands in for the Schur complement
+        Sl.base = c->opA00.base + 3 * (c->opA01.base - c->opA00.base);     // block (1,1) = 3 planes after (0,0)
+        Sl.slot_stride = c->opA00.slot_stride;
+        if (c->opt.decoup == 0) Sl.base = c->J.p + (long)(c->b + 1) * c->g.ntot;
+    }
+    if (cptr) TP_REQUIRE(Sl.base, "pc_cptr needs the S~ operator (assemble with want_schur)");
     if (c->dist && c->amg_p->dist_levels == 0) {
         const size_t ng = (size_t)c->gfull.ntot;
         if (c->gA00.n < 7 * ng) {
@@ -117,7 +124,7 @@ void pc_setup(tp_ctx *c) {
                              (uintptr_t)c->Sm.p, (uintptr_t)c->ilu.fwd.p, (uintptr_t)c->amg_p, (uintptr_t)c->amg_T,
                              (uintptr_t)c->w1.p, (uintptr_t)c->w3.p, (uintptr_t)c->w4.p, (uintptr_t)c->dcoef.p,
                              (uintptr_t)c->opt.amg_nu, (uintptr_t)c->opt.pc_kind, (uintptr_t)c->opt.decoup,
-                             (uintptr_t)c->opt.amg_single, (uintptr_t)c->opt.amg_gather_cells, (uintptr_t)c->opt.amg_full_levels, (uintptr_t)c->opt.amg_coarse_pre, (uintptr_t)c->opt.amg_coarse_post,
+                             (uintptr_t)c->opt.amg_single, (uintptr_t)c->opt.amg_gather_cells, (uintptr_t)c->opt.schur_a11, (uintptr_t)c->opt.amg_full_levels, (uintptr_t)c->opt.amg_coarse_pre, (uintptr_t)c->opt.amg_coarse_post,
                              (uintptr_t)c->ilu.ntiles, (uintptr_t)c->ilu.nsteps};
     uintptr_t h = 1469598103934665603ull;
     for (uintptr_t v : sig) h = (h ^ v) * 1099511628211ull;

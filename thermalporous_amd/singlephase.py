@@ -75,7 +75,13 @@ class SinglePhase(ThermalModel):
                             "fieldsplit_1_pc_type": "python",
                             "fieldsplit_1_pc_python_type": "thermalporous.preconditioners.ConvDiffSchurPC",
                             "fieldsplit_1_schur": v_cycle}
-        presets = {"pc_cpr": pc_cpr,
+        pc_fieldsplit_a11 = {"pc_type": "fieldsplit",    # (:331-338) A_TT stands in for the Schur complement
+                             "pc_fieldsplit_type": "schur",
+                             "pc_fieldsplit_schur_fact_type": "FULL",
+                             "pc_fieldsplit_schur_precondition": "a11",
+                             "fieldsplit_0": v_cycle,
+                             "fieldsplit_1": v_cycle}
+        presets = {"pc_fieldsplit_a11": pc_fieldsplit_a11, "pc_cpr": pc_cpr,
                    "pc_cpr_QI": {**pc_cpr, "sub_0_cpr_decoup": "QI"},      # (:353)
                    "pc_cpr_TI": {**pc_cpr, "sub_0_cpr_decoup": "TI"},      # (:354)
                    "pc_fieldsplit_cd": pc_fieldsplit_cd,

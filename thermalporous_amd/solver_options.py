@@ -41,6 +41,7 @@ def engine_options(solver_parameters, model_name, decoup="No"):
     sp = _flatten(dict(solver_parameters))
     o = dict(DEFAULT_OPTS)
     o["decoup"] = decoup
+    o["schur_a11"] = False
     build_keys = ("amg_omega", "amg_nu", "amg_min_cells", "amg_full_levels", "amg_coarse_pre", "amg_coarse_post", "amg_single",
                   "amg_gather_cells", "ilu_tile")
     for k in build_keys:
@@ -59,10 +60,13 @@ def engine_options(solver_parameters, model_name, decoup="No"):
             o[k_dst] = sp[k_src]
     if sp.get("pc_type") == "fieldsplit":
         # pc_fieldsplit_cd (singlephase.py:309-319): Schur FULL on (p,T), V-cycle on A_pp, ConvDiffSchurPC on S
+        a11 = sp.get("pc_fieldsplit_schur_precondition") == "a11" and sp.get("fieldsplit_1_pc_type") == "hypre"
         if sp.get("pc_fieldsplit_type") != "schur" or str(sp.get("pc_fieldsplit_schur_fact_type", "")).upper() != "FULL" \
-                or not str(sp.get("fieldsplit_1_pc_python_type", "")).endswith("ConvDiffSchurPC"):
-            raise NotImplementedError("the only fieldsplit preconditioner on the hot path is pc_fieldsplit_cd "
-                                      "(schur FULL with ConvDiffSchurPC); selfp/a11 variants are not")
+                or not (a11 or (str(sp.get("fieldsplit_1_pc_python_type", "")).endswith("ConvDiffSchurPC")
+                                and "pc_fieldsplit_schur_precondition" not in sp)):
+            raise NotImplementedError("fieldsplit preconditioners on the hot path: pc_fieldsplit_cd (schur FULL with "
+                                      "ConvDiffSchurPC) and pc_fieldsplit_a11; selfp / additive variants are not")
+        o["schur_a11"] = bool(a11)
         if model_name == "Two-phase":
             raise NotImplementedError("pc_fieldsplit_cd is the single-phase block preconditioner")
         if o["decoup"] != "No":
@@ -118,6 +122,10 @@ def engine_options(solver_parameters, model_name, decoup="No"):
         if sp.get("sub_0_cpr_stage1_pc_type") != "fieldsplit":
             raise NotImplementedError("CPTRStage1PC is implemented with the fieldsplit-Schur stage-1 solver of "
                                       "pc_cptr; system-AMG/LU variants (pc_cptramg*, pc_cptrlu*) are not")
+        pre = sp.get("sub_0_cpr_stage1_pc_fieldsplit_schur_precondition")
+        if pre not in (None, "a11"):
+            raise NotImplementedError("Schur preconditioning %r (only the ConvDiffSchurTwoPhasesPC operator and a11)" % pre)
+        o["schur_a11"] = pre == "a11"                   # pc_cptr_a11 (twophase.py:598-616)
     else:
         raise NotImplementedError("sub_0_pc_python_type %r" % pytype)
     if o["decoup"] not in ("No", "QI", "TI", "QI_temp", "TI_temp"):

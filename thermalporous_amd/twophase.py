@@ -120,7 +120,10 @@ class TwoPhase(ThermalModel):
                          "sub_1_sub_pc_type": "ilu",
                          "sub_1_sub_pc_factor_levels": 0,
                          "mat_type": "aij"}
-        presets = {"pc_cptr": pc_cptr, "pc_cpr": pc_cpr,
+        pc_cptr_a11 = {k: v for k, v in pc_cptr.items() if not k.startswith("sub_0_cpr_stage1_fieldsplit_1")}   # (:598-616)
+        pc_cptr_a11.update({"sub_0_cpr_stage1_pc_fieldsplit_schur_precondition": "a11",
+                            "sub_0_cpr_stage1_fieldsplit_1": v_cycle, "sub_1_pc_bjacobi_blocks": 1})
+        presets = {"pc_cptr": pc_cptr, "pc_cptr_a11": pc_cptr_a11, "pc_cpr": pc_cpr,
                    "pc_cpr_QI": {**pc_cpr, "sub_0_cpr_decoup": "QI"},      # (:594)
                    "pc_cpr_TI": {**pc_cpr, "sub_0_cpr_decoup": "TI"},      # (:595)
                    "pc_cpr_QI_temp": {**pc_cpr, "sub_0_cpr_decoup": "QI_temp"},      # (:596)
