@@ -380,7 +380,9 @@ __global__ __launch_bounds__(256) void k_amg_prolong_add(LevelDevT<R> Lf, GridDe
 // ---- the tail: all small levels in one workgroup --------------------------------------------------------
 template <class R>
 __global__ __launch_bounds__(1024) void k_amg_tail(const LevelDevT<R> *lv, int l0, int nlev, int nu, int ncoarse,
-                                                   const double *Minv, const double *b_top, double *e_top) {
+                                                   const double *Minv, const double *b_top, double *e_top,
+                                                   int lds_doubles) {
+    extern __shared__ double dyn[];          // 4 x lds_doubles: the b, e, x, x2 vectors of every tail level
     const int T = blockDim.x, t = threadIdx.x;
     // level descriptors live in LDS: every phase below starts with LDS reads, not a global round trip
     static_assert(sizeof(LevelDevT<R>) % sizeof(long) == 0, "LevelDev must be a whole number of words");
@@ -389,10 +391,46 @@ __global__ __launch_bounds__(1024) void k_amg_tail(const LevelDevT<R> *lv, int l
         const int wpl = (int)(sizeof(LevelDevT<R>) / sizeof(long));
         const long *src = reinterpret_cast<const long *>(lv);
         for (int i = l0 * wpl + t; i < nlev * wpl; i += T) slv_raw[i] = src[i];
+        if (lds_doubles > 0)
+            for (int i = t; i < 4 * lds_doubles; i += T) dyn[i] = 0.0;      // (halo planes must read as zero)
+        __syncthreads();
+    }
+    if (lds_doubles > 0) {
+        // the tail's vectors live in LDS: a phase boundary is then an LDS store + barrier + LDS load instead of a
+        // global store that must drain (s_waitcnt vmcnt(0)) before the barrier and an L2 round trip after it.
+        // Done by re-pointing the LDS copy of the level descriptors; the sweeps below do not change.
+        if (t == 0) {
+            LevelDevT<R> *w = reinterpret_cast<LevelDevT<R> *>(slv_raw);
+            long off = 0;
+            for (int l = l0; l < nlev; ++l) {
+                w[l].b = dyn + off;
+                w[l].e = dyn + lds_doubles + off;
+                w[l].x = dyn + 2 * lds_doubles + off;
+                w[l].x2 = dyn + 3 * lds_doubles + off;
+                off += w[l].g.ntot;
+            }
+        }
         __syncthreads();
     }
     lv = reinterpret_cast<const LevelDevT<R> *>(slv_raw);
     (void)nu;
+    // Touch every read-only array of the tail (operators, inverse diagonals, weights, the dense inverse) NOW, all
+    // at once: they were written by the set-up long ago and have left the L2; otherwise each of the ~10 phases below
+    // starts with its own HBM + TLB round trip (~3 us of a ~4 us phase).
+    {
+        double sink = 0.0;
+        for (int l = l0; l < nlev; ++l) {
+            const LevelDevT<R> &L = lv[l];
+            for (long i = L.g.np + t; i < L.g.np + L.g.nown; i += T) {
+#pragma unroll
+                for (int k = 0; k < 7; ++k) sink += (double)L.op.slot(k)[i];
+                sink += (double)L.invd[i];
+                if (L.axis >= 0) sink += (double)L.wm[i] + (double)L.wp[i];
+            }
+        }
+        for (int i = t; i < ncoarse * ncoarse; i += T) sink += Minv[i];
+        if (sink == 1.2345678e-300) e_top[0] = sink;       // never true: keeps the loads alive
+    }
     // down-sweep
     for (int l = l0; l < nlev - 1; ++l) {
         const LevelDevT<R> L = lv[l];
@@ -421,10 +459,17 @@ __global__ __launch_bounds__(1024) void k_amg_tail(const LevelDevT<R> *lv, int l
         const LevelDevT<R> Lc = lv[nlev - 1];
         const double *b = (nlev - 1 == l0) ? b_top : Lc.b;
         double *e = (nlev - 1 == l0) ? e_top : Lc.e;
-        for (int r = t; r < ncoarse; r += T) {
+        // 16 lanes per row: coalesced reads of the row, 4 independent products per lane, shuffle reduction
+        // (one lane per row walked its 64 entries one dependent L2 round trip at a time: ~30 us of a 44 us kernel)
+        const int grp = t >> 4, gl = t & 15;
+        for (int r = grp; r < ncoarse; r += T >> 4) {
             double s = 0.0;
-            for (int q = 0; q < ncoarse; ++q) s += Minv[(long)r * ncoarse + q] * b[Lc.g.np + q];
-            e[Lc.g.np + r] = s;
+            for (int q = gl; q < ncoarse; q += 16) s += Minv[(long)r * ncoarse + q] * b[Lc.g.np + q];
+            s += __shfl_xor(s, 8, 64);
+            s += __shfl_xor(s, 4, 64);
+            s += __shfl_xor(s, 2, 64);
+            s += __shfl_xor(s, 1, 64);
+            if (gl == 0) e[Lc.g.np + r] = s;
         }
         __syncthreads();
     }
@@ -546,6 +591,19 @@ void amg_build(tp_ctx *c, Amg *&amg, const GridDev &g0, const double strength[3]
     for (size_t l = (size_t)amg->dist_levels; l < amg->lv.size(); ++l)
         if (amg->lv[l]->g.nown <= tail_cells) { amg->tail_level = (int)l; break; }
     amg->lvdev.alloc(amg->lv.size() * sizeof(LevelDevT<double>));
+    // the tail keeps its vectors (b, e, x, x2 of every level) in LDS when they fit next to the level descriptors
+    long tot = 0;
+    for (size_t l = (size_t)amg->tail_level; l < amg->lv.size(); ++l) tot += amg->lv[l]->g.ntot;
+    const bool lds_on = !(getenv("TP_AMG_TAIL_LDS") && atoi(getenv("TP_AMG_TAIL_LDS")) == 0);
+    amg->tail_lds = (lds_on && 4 * tot * (long)sizeof(double) <= 120 * 1024) ? (int)tot : 0;
+    if (getenv("TP_DEBUG")) fprintf(stderr, "[tp] amg tail: level %d of %zu, %ld doubles per vector set, lds %d\n", amg->tail_level, amg->lv.size(), tot, amg->tail_lds);
+    if (amg->tail_lds > 0) {
+        const int bytes = 4 * amg->tail_lds * (int)sizeof(double);
+        TP_HIP(hipFuncSetAttribute(reinterpret_cast<const void *>(&k_amg_tail<double>),
+                                   hipFuncAttributeMaxDynamicSharedMemorySize, bytes));
+        TP_HIP(hipFuncSetAttribute(reinterpret_cast<const void *>(&k_amg_tail<float>),
+                                   hipFuncAttributeMaxDynamicSharedMemorySize, bytes));
+    }
 }
 
 // level l+1 as its parent level l sees it.  Below the last distributed level that is this rank's planes of the
@@ -684,8 +742,9 @@ static void vcycle_impl(tp_ctx *c, Amg *amg, const double *b, double *x) {
         const double *bt = (lt == 0) ? b : Lt->b.p;
         double *et = (lt == 0) ? x : Lt->e.p;
         const int n = amg->ncoarse;
-        hipLaunchKernelGGL(k_amg_tail<R>, dim3(1), dim3(1024), 0, c->stream, (const LevelDevT<R> *)amg->lvdev.p, lt, nlev,
-                           c->opt.amg_nu, n, (const double *)(amg->coarse_inv.p + (size_t)n * n), bt, et);
+        hipLaunchKernelGGL(k_amg_tail<R>, dim3(1), dim3(1024), (size_t)4 * amg->tail_lds * sizeof(double), c->stream,
+                           (const LevelDevT<R> *)amg->lvdev.p, lt, nlev, c->opt.amg_nu, n,
+                           (const double *)(amg->coarse_inv.p + (size_t)n * n), bt, et, amg->tail_lds);
     }
     // up-sweep over the big levels
     for (int l = lt - 1; l >= 0; --l) {

@@ -127,6 +127,7 @@ struct Amg {
     int ncoarse = 0;
     bool single = false;       // operators / weights / inverse diagonals stored in fp32
     int tail_level = 0;        // first level handled by the single-workgroup tail kernel
+    int tail_lds = 0;          // doubles per LDS-resident vector set of the tail (0: tail vectors stay in global memory)
     long fuse_below = 200000;  // levels with fewer cells use the fused (launch-saving) kernels
     // multi-GPU: levels [0, dist_levels) live on this rank's slab (halo exchanges between sweeps), the levels
     // below on the gathered global grid, replicated on every rank.  0 = the whole hierarchy is replicated.
