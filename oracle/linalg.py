@@ -185,7 +185,7 @@ class SemiAMG:
     """
 
     def __init__(self, n, strength, omega=0.8, min_cells=64, nu=1, max_levels=40, full_levels=99, coarse_pre=None,
-                 coarse_post=None, single=False):
+                 coarse_post=None, single=False, tail_post=None):
         """V(nu,nu) on the first `full_levels` levels, V(coarse_pre, coarse_post) below (the coarse levels of
         the GPU cycle are launch-latency bound: dropping their pre-smoothing costs no Krylov iterations)."""
         self.n = tuple(n)
@@ -194,6 +194,8 @@ class SemiAMG:
         self.full_levels = full_levels
         self.coarse_pre = nu if coarse_pre is None else coarse_pre
         self.coarse_post = nu if coarse_post is None else coarse_post
+        # levels of <= 1024 cells (the GPU's single-workgroup tail) may smooth more: V(coarse_pre, tail_post)
+        self.tail_post = self.coarse_post if tail_post is None else tail_post
         self.sched = self._schedule(n, strength, min_cells, max_levels)
 
     @staticmethod
@@ -311,7 +313,10 @@ class SemiAMG:
             if self.coarse is None:
                 return b / self.coarse_scalar
             return self.coarse.solve(b.reshape(-1)).reshape(b.shape)
-        pre, post = (self.nu, self.nu) if lvl < self.full_levels else (self.coarse_pre, self.coarse_post)
+        if lvl < self.full_levels:
+            pre, post = self.nu, self.nu
+        else:
+            pre, post = self.coarse_pre, (self.tail_post if b.size <= 1024 else self.coarse_post)
         if pre == 0:
             x, r = np.zeros_like(b), b
         else:
@@ -423,7 +428,8 @@ class TwoStagePC:
         self.slabs = slab_ranges(n[2], int(opts.get("nslabs", 1)))
         kw = dict(omega=opts["amg_omega"], min_cells=opts["amg_min_cells"], nu=opts["amg_nu"],
                   full_levels=opts.get("amg_full_levels", 99), coarse_pre=opts.get("amg_coarse_pre"),
-                  coarse_post=opts.get("amg_coarse_post"), single=opts.get("amg_single", False))
+                  coarse_post=opts.get("amg_coarse_post"), single=opts.get("amg_single", False),
+                  tail_post=opts.get("amg_tail_post"))
 
         # coarsening schedule from the mean interior-face transmissibility per axis
         st = [float(np.mean(prob.TK[a][_lo(a)])) if n[a] > 1 else 0.0 for a in range(3)]

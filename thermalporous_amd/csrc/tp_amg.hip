@@ -518,8 +518,11 @@ static LevelDevT<R> dev_of(const AmgLevel *L, int level, const tp_options &o) {
     LevelDevT<R> d;
     const int nu = std::max(1, o.amg_nu);
     const bool full = level < o.amg_full_levels;
+    // cycle shape: V(nu,nu) on the first levels, V(coarse_pre, coarse_post) below, and V(coarse_pre, tail_post) on
+    // the levels of <= 1024 cells (a property of the level size, so that the oracle can mirror it)
+    const bool small = L->g.np * (long)L->g.gn2 <= 1024;
     d.pre = full ? nu : std::max(0, o.amg_coarse_pre);
-    d.post = full ? nu : std::max(1, o.amg_coarse_post);
+    d.post = full ? nu : std::max(1, small ? o.amg_tail_post : o.amg_coarse_post);
     d.pad_ = 0;
     d.g = L->g;
     d.op.base = (R *)L->op.base;
