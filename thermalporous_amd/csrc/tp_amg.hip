@@ -601,7 +601,7 @@ void amg_build(tp_ctx *c, Amg *&amg, const GridDev &g0, const double strength[3]
     amg->tail_lds = (lds_on && 4 * tot * (long)sizeof(double) <= 120 * 1024) ? (int)tot : 0;
     if (getenv("TP_DEBUG")) fprintf(stderr, "[tp] amg tail: level %d of %zu, %ld doubles per vector set, lds %d\n", amg->tail_level, amg->lv.size(), tot, amg->tail_lds);
     if (amg->tail_lds > 0) {
-        const int bytes = 4 * amg->tail_lds * (int)sizeof(double);
+        const int bytes = 120 * 1024;      // per-function limit shared by every hierarchy: always the maximum
         TP_HIP(hipFuncSetAttribute(reinterpret_cast<const void *>(&k_amg_tail<double>),
                                    hipFuncAttributeMaxDynamicSharedMemorySize, bytes));
         TP_HIP(hipFuncSetAttribute(reinterpret_cast<const void *>(&k_amg_tail<float>),
