@@ -122,7 +122,8 @@ int tp_comm_init_local(tp_ctx *ctx, void *group);
  * transmissibilities H(K)|e|/Delta_h (singlephase.py:98-103). */
 int tp_set_field(tp_ctx *ctx, const char *name, const double *host, int64_t n);
 int tp_finalize_fields(tp_ctx *ctx);
-int tp_set_sources(tp_ctx *ctx, int32_t n, const tp_source *entries);
+int tp_set_sources(tp_ctx *ctx, int32_t n, const tp_source *entries);   /* wells/heaters: wellcase.py:78-108,171-266,
+                                                                           heatercase.py:63-77, sourceterms.py:77-84,155-269 */
 
 /* state u, old state u_ (thermalmodel.py:93-94,296), time step (thermalmodel.py:13). */
 int tp_set_state(tp_ctx *ctx, const double *u_host);      /* b*ntot doubles */
@@ -136,7 +137,8 @@ int tp_restore_state(tp_ctx *ctx);                          /* u <- u_  (thermal
 int tp_saturation_range(tp_ctx *ctx, double *smin, double *smax);
 int tp_clamp_saturation(tp_ctx *ctx);
 
-/* assembly: F(u) and J = dF/du (what TSFC/PyOP2 kernels + MatSetValues do in the reference). */
+/* assembly: F(u) and J = dF/du (what TSFC/PyOP2 kernels + MatSetValues do in the reference for the forms
+ * singlephase.py:60-273 / twophase.py:67-411 behind self.solver.solve(), thermalmodel.py:165). */
 int tp_residual(tp_ctx *ctx, double *norm2);               /* R <- F(u); ||F||_2 over all ranks */
 int tp_jacobian(tp_ctx *ctx);                              /* R, J (and S~ for pc_cptr) <- at u */
 int tp_get_residual(tp_ctx *ctx, double *host);            /* b*ntot */
@@ -150,19 +152,21 @@ int tp_vec_set(tp_ctx *ctx, int32_t id, const double *host);
 int tp_vec_get(tp_ctx *ctx, int32_t id, double *host);
 int tp_vec_copy_residual(tp_ctx *ctx, int32_t id);        /* vec <- R */
 
-/* operators (PETSc MatMult AIJ / PCApply in the reference) */
+/* operators (PETSc MatMult AIJ / PCApply in the reference: option dicts singlephase.py:303-354,
+ * twophase.py:478-482,531-597) */
 int tp_spmv(tp_ctx *ctx, int32_t x, int32_t y);            /* y = J x */
 int tp_pc_setup(tp_ctx *ctx);                              /* PCSetUp: decoupling, AMG setup, ILU factor */
 int tp_pc_apply(tp_ctx *ctx, int32_t x, int32_t y);        /* composite multiplicative (stage1, ILU0) */
 int tp_stage1_update(tp_ctx *ctx);                         /* CPRStage1PC/CPTRStage1PC.update (preconditioners.py:875,1545) */
 int tp_stage1_apply(tp_ctx *ctx, int32_t x, int32_t y);    /* ....apply (preconditioners.py:881,1550) */
-int tp_ilu0_factor(tp_ctx *ctx);                           /* sub_1: bjacobi + ILU(0) numeric factorisation */
+int tp_ilu0_factor(tp_ctx *ctx);                           /* sub_1: bjacobi + ILU(0) numeric factorisation (singlephase.py:348-349) */
 int tp_ilu0_solve(tp_ctx *ctx, int32_t x, int32_t y);
-int tp_amg_setup(tp_ctx *ctx, int32_t which);              /* 0: pressure operator, 1: S~ */
+int tp_amg_setup(tp_ctx *ctx, int32_t which);              /* v_cycle dict (singlephase.py:303-307); 0: pressure operator, 1: S~ */
 int tp_amg_vcycle(tp_ctx *ctx, int32_t which, int32_t field_b, int32_t b, int32_t field_x, int32_t x);
 int tp_schur_apply(tp_ctx *ctx, int32_t x, int32_t y);     /* ConvDiffSchur*PC.apply: one V-cycle on S~, field 1 */
 
-/* Krylov / Newton (PETSc KSP fgmres + SNES newtonls in the reference) */
+/* Krylov / Newton (PETSc KSP fgmres + SNES newtonls in the reference: twophase.py:416-433, singlephase.py:289-301;
+ * reasons use PETSc's numbering so that the host raises ConvergenceError where Firedrake does, thermalmodel.py:170) */
 int tp_fgmres(tp_ctx *ctx, int32_t b, int32_t x, int32_t *its, int32_t *reason, double *rnorm);
 int tp_newton_solve(tp_ctx *ctx, tp_solve_info *info);
 
