@@ -204,6 +204,11 @@ tp_ctx::~tp_ctx() {
     if (comm) ncclCommDestroy((ncclComm_t)comm);
     if (ev0) (void)hipEventDestroy(ev0);
     if (ev1) (void)hipEventDestroy(ev1);
+    for (int i = 0; i < 2; ++i) {
+        if (aux[i]) (void)hipStreamDestroy(aux[i]);
+        if (ev_join[i]) (void)hipEventDestroy(ev_join[i]);
+    }
+    if (ev_fork) (void)hipEventDestroy(ev_fork);
     if (stream) (void)hipStreamDestroy(stream);
 }
 
@@ -270,6 +275,11 @@ int tp_create(const tp_grid *grid, const tp_params *prm, const tp_options *opt, 
     c->vol = grid->h[0] * grid->h[1] * grid->h[2];
     derive_params(c);
     TP_HIP(hipStreamCreate(&c->stream));
+    for (int i = 0; i < 2; ++i) {
+        TP_HIP(hipStreamCreateWithFlags(&c->aux[i], hipStreamNonBlocking));
+        TP_HIP(hipEventCreateWithFlags(&c->ev_join[i], hipEventDisableTiming));
+    }
+    TP_HIP(hipEventCreateWithFlags(&c->ev_fork, hipEventDisableTiming));
     TP_HIP(hipEventCreate(&c->ev0));
     TP_HIP(hipEventCreate(&c->ev1));
     const size_t nt = (size_t)c->g.ntot, B = (size_t)c->b;

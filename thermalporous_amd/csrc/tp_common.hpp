@@ -157,6 +157,9 @@ struct tp_ctx {
     int nph = 1, b = 2, device = 0;
     hipStream_t stream = nullptr;
     hipEvent_t ev0 = nullptr, ev1 = nullptr;
+    // pc_setup forks: the two AMG set-ups and the ILU factorisation are independent chains of small kernels
+    hipStream_t aux[2] = {nullptr, nullptr};
+    hipEvent_t ev_fork = nullptr, ev_join[2] = {nullptr, nullptr};
     double dt = 0.0, vol = 0.0;
     bool fields_ready = false, have_old = false, jac_ready = false, pc_ready = false;
     // fields

@@ -112,12 +112,34 @@ void pc_setup(tp_ctx *c) {
             G.base = c->gSm.p;
             amg_setup(c, c->amg_T, G);
         }
-    } else {
+    } else if (c->dist) {
         amg_setup(c, c->amg_p, c->opA00);
         if (cptr) amg_setup(c, c->amg_T, Sl);
+    } else {
+        // one GPU: the AMG set-ups (2 x ~35 launch-latency-bound kernels) and the ILU factorisation are
+        // independent -> three concurrent streams, joined before anything uses the preconditioner.
+        // (not with RCCL in the set-up: one communicator must not be driven from two streams at once)
+        hipStream_t main = c->stream;
+        struct Restore { tp_ctx *c; hipStream_t s; ~Restore() { c->stream = s; } } restore{c, main};   // also on a throw
+        TP_HIP(hipEventRecord(c->ev_fork, main));
+        TP_HIP(hipStreamWaitEvent(c->aux[0], c->ev_fork, 0));
+        c->stream = c->aux[0];
+        amg_setup(c, c->amg_p, c->opA00);
+        TP_HIP(hipEventRecord(c->ev_join[0], c->aux[0]));
+        if (cptr) {
+            TP_HIP(hipStreamWaitEvent(c->aux[1], c->ev_fork, 0));
+            c->stream = c->aux[1];
+            amg_setup(c, c->amg_T, Sl);
+            TP_HIP(hipEventRecord(c->ev_join[1], c->aux[1]));
+        }
+        c->stream = main;
+        ilu_factor(c);
+        TP_HIP(hipStreamWaitEvent(main, c->ev_join[0], 0));
+        if (cptr) TP_HIP(hipStreamWaitEvent(main, c->ev_join[1], 0));
+        c->pc_ready = true;
     }
     // stage 2: numeric block-ILU(0) of every tile of this rank's slab
-    ilu_factor(c);
+    if (c->dist) ilu_factor(c);
     c->pc_ready = true;
     // the captured pc_apply graph bakes in buffer addresses and options: invalidate it when any changes
     const uintptr_t sig[] = {(uintptr_t)c->opA00.base, (uintptr_t)c->opA01.base, (uintptr_t)c->opA10.base,
