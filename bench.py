@@ -122,7 +122,7 @@ def main():
     nits, lits = model.total_nits - n0, model.total_lits - l0
 
     # roofline of the dominant streaming kernel of one Krylov iteration: the 7-point 3x3-block SpMV
-    eng.lib.tp_jacobian(eng.ctx)
+    eng._ck(eng.lib.tp_jacobian(eng.ctx))
     eng.pc_setup()
     ncell_local = eng.n[0]*eng.n[1]*eng.n[2]
     ms = eng.time_kernel(0, 50)
