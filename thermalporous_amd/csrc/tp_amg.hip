@@ -566,23 +566,38 @@ void amg_build(tp_ctx *c, Amg *&amg, const GridDev &g0, const double strength[3]
         // every other level is the whole box with dead halo planes
         L->g = still ? make_grid(m[0], m[1], cur[me].second - cur[me].first, m[2], cur[me].first)
                      : make_grid(m[0], m[1], m[2], m[2], 0);
-        const size_t nt = (size_t)L->g.ntot;
-        // operator/weight buffers are sized for doubles and hold floats when amg_single (slot stride in elements)
-        if (l > 0 || amg->single) {
-            L->A.alloc(7 * nt);
-            L->op.base = L->A.p;
-            L->op.slot_stride = (long)nt;
-        }
-        L->invd.alloc(nt);
-        L->b.alloc(nt); L->x.alloc(nt); L->x2.alloc(nt); L->e.alloc(nt);
         if (l < amg->sched.size()) {
             L->axis = amg->sched[l];
-            L->wm.alloc(nt); L->wp.alloc(nt);
             m[L->axis] = (m[L->axis] + 1) / 2;
             if (L->axis == 2)
                 for (auto &q : cur) q = {(q.first + 1) / 2, (q.second + 1) / 2};     // even global planes survive
         }
         amg->lv.push_back(L);
+    }
+    // carve every level's buffers out of one arena (32-double = 256-byte aligned slices)
+    {
+        auto pad = [](size_t v) { return (v + 31) & ~(size_t)31; };
+        size_t total = 0;
+        for (size_t l = 0; l < amg->lv.size(); ++l) {
+            const size_t nt = pad((size_t)amg->lv[l]->g.ntot);
+            total += ((l > 0 || amg->single) ? 7 : 0) * nt + 5 * nt + (amg->lv[l]->axis >= 0 ? 2 * nt : 0);
+        }
+        amg->arena.alloc(total);
+        double *q = amg->arena.p;
+        auto take = [&](DBuf<double> &d, size_t nd, size_t step) { d.view(q, nd); q += step; };
+        for (size_t l = 0; l < amg->lv.size(); ++l) {
+            AmgLevel *L = amg->lv[l];
+            const size_t nt = (size_t)L->g.ntot, ntp = pad(nt);
+            // operator/weight buffers are sized for doubles and hold floats when amg_single (slot stride in elements)
+            if (l > 0 || amg->single) {
+                take(L->A, 7 * nt, 7 * ntp);
+                L->op.base = L->A.p;
+                L->op.slot_stride = (long)nt;
+            }
+            take(L->invd, nt, ntp);
+            take(L->b, nt, ntp); take(L->x, nt, ntp); take(L->x2, nt, ntp); take(L->e, nt, ntp);
+            if (L->axis >= 0) { take(L->wm, nt, ntp); take(L->wp, nt, ntp); }
+        }
     }
     amg->ncoarse = (int)amg->lv.back()->g.nown;
     TP_REQUIRE(amg->ncoarse <= 1024, "coarsest AMG grid too large for the dense solve");

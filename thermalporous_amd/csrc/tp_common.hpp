@@ -92,6 +92,7 @@ template <class T>
 struct DBuf {
     T *p = nullptr;
     size_t n = 0;
+    bool owned = true;
     void alloc(size_t n_) {
         free();
         n = n_;
@@ -100,10 +101,16 @@ struct DBuf {
             TP_HIP(hipMemset(p, 0, n * sizeof(T)));
         }
     }
+    // a slice of somebody else's allocation (zeroed by its owner)
+    void view(T *q, size_t n_) {
+        free();
+        p = q; n = n_; owned = false;
+    }
     void free() {
-        if (p) (void)hipFree(p);
+        if (p && owned) (void)hipFree(p);
         p = nullptr;
         n = 0;
+        owned = true;
     }
     ~DBuf() { free(); }
     DBuf() = default;
@@ -122,6 +129,9 @@ struct AmgLevel {
 };
 
 struct Amg {
+    // one allocation for every buffer of every level: the coarse levels are tiny, and with one hipMalloc each
+    // (~150 of them) every small kernel of the cycle starts with TLB misses on half a dozen scattered pages
+    DBuf<double> arena;
     std::vector<AmgLevel *> lv;
     DBuf<double> coarse_inv;   // dense inverse on the coarsest grid
     int ncoarse = 0;
