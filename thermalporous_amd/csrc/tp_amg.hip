@@ -85,22 +85,23 @@ __global__ void k_amg_coarsen(GridDev gf, GridDev gc, StencilT<R> A, int axis, c
     const long stride = axis == 0 ? 1 : (axis == 1 ? gf.n0 : gf.np);
     const long f = gf.np + (long)F[0] + (long)gf.n0 * F[1] + gf.np * F[2];
     const bool hm = F[axis] - 1 >= 0 || open_lo(gf, axis), hp = F[axis] + 1 < nfa || open_hi(gf, axis);
-    const long gm = f - stride, gp = f + stride;
-    const double Pm = hm ? wp[gm] : 0.0;     // P[g-, I] = w+(g-)
-    const double Pp = hp ? wm[gp] : 0.0;     // P[g+, I] = w-(g+)
+    const long gm = hm ? f - stride : f, gp = hp ? f + stride : f;      // clamped: every load below is unconditional
+    const double Pm = hm ? (double)wp[gm] : 0.0;     // P[g-, I] = w+(g-)
+    const double Pp = hp ? (double)wm[gp] : 0.0;     // P[g+, I] = w-(g+)
+    const double Wm = hm ? (double)wm[gm] : 0.0, Wp = hp ? (double)wp[gp] : 0.0;
     double rho_f = 0.0, rho_m = 0.0, rho_p = 0.0;
     double out[7];
     double offsum = 0.0;
 #pragma unroll
     for (int s = 0; s < 7; ++s) {
         const double af = A.slot(s)[f];
-        const double am = hm ? A.slot(s)[gm] : 0.0;
-        const double ap = hp ? A.slot(s)[gp] : 0.0;
+        const double lm = A.slot(s)[gm], lp = A.slot(s)[gp];
+        const double am = hm ? lm : 0.0, ap = hp ? lp : 0.0;
         rho_f += af; rho_m += am; rho_p += ap;
         if (s == 0) continue;
         double v;
-        if (s == 1 + 2 * axis)      v = af * (hm ? wm[gm] : 0.0);
-        else if (s == 2 + 2 * axis) v = af * (hp ? wp[gp] : 0.0);
+        if (s == 1 + 2 * axis)      v = af * Wm;
+        else if (s == 2 + 2 * axis) v = af * Wp;
         else                        v = af + Pm * am + Pp * ap;
         out[s] = v;
         offsum += v;
@@ -254,10 +255,10 @@ __device__ __forceinline__ double resid_restrict_cell(const LevelDevT<R> &Lf, co
     const int nfa = a == 0 ? gf.n0 : (a == 1 ? gf.n1 : gf.n2);
     const long stride = a == 0 ? 1 : (a == 1 ? gf.n0 : gf.np);
     const long f = gf.np + (long)F[0] + (long)gf.n0 * F[1] + gf.np * F[2];
-    double v = resid_at(Lf, b, x, f);
-    if (F[a] - 1 >= 0) v += Lf.wp[f - stride] * resid_at(Lf, b, x, f - stride);
-    if (F[a] + 1 < nfa) v += Lf.wm[f + stride] * resid_at(Lf, b, x, f + stride);
-    return v;
+    const bool hm = F[a] - 1 >= 0, hp = F[a] + 1 < nfa;
+    const long fm = hm ? f - stride : f, fp = hp ? f + stride : f;
+    const double vm = (double)Lf.wp[fm] * resid_at(Lf, b, x, fm), vp = (double)Lf.wm[fp] * resid_at(Lf, b, x, fp);
+    return resid_at(Lf, b, x, f) + (hm ? vm : 0.0) + (hp ? vp : 0.0);
 }
 
 // (P^T r) at coarse cell tidc, r given as a vector
@@ -273,31 +274,11 @@ __device__ __forceinline__ double restrict_cell(const LevelDevT<R> &Lf, const Gr
     const int nfa = a == 0 ? gf.n0 : (a == 1 ? gf.n1 : gf.n2);
     const long stride = a == 0 ? 1 : (a == 1 ? gf.n0 : gf.np);
     const long f = gf.np + (long)F[0] + (long)gf.n0 * F[1] + gf.np * F[2];
-    double v = r[f];
-    if (F[a] - 1 >= 0 || open_lo(gf, a)) v += Lf.wp[f - stride] * r[f - stride];
-    if (F[a] + 1 < nfa || open_hi(gf, a)) v += Lf.wm[f + stride] * r[f + stride];
-    return v;
-}
-
-// (P ec) at fine cell (F0,F1,F2); along the slab axis F2 may be a halo plane (-1 or n2) and the parents may sit in
-// the coarse halo planes
-template <class R>
-__device__ __forceinline__ double prolong_at(const LevelDevT<R> &Lf, const GridDev &gc, const double *__restrict__ ec,
-                                             int F0, int F1, int F2) {
-    const int a = Lf.axis;
-    const int Fa = a == 0 ? F0 : (a == 1 ? F1 : F2);
-    const int p = par_of(Lf.g, a);
-    const int Ia = (Fa - p) >> 1;                   // floor: the C point itself, or the left parent of an F point
-    int I0 = F0, I1 = F1, I2 = F2;
-    if (a == 0) I0 = Ia; else if (a == 1) I1 = Ia; else I2 = Ia;
-    const long ci = gc.np + (long)I0 + (long)gc.n0 * I1 + gc.np * I2;
-    if (((Fa + p) & 1) == 0) return ec[ci];
-    const long c = Lf.g.np + (long)F0 + (long)Lf.g.n0 * F1 + Lf.g.np * F2;
-    const long cs = a == 0 ? 1 : (a == 1 ? gc.n0 : gc.np);
-    const int nca = a == 0 ? gc.n0 : (a == 1 ? gc.n1 : gc.n2);
-    double e = Lf.wm[c] * ec[ci];
-    if (Ia + 1 < nca || open_hi(gc, a)) e += Lf.wp[c] * ec[ci + cs];
-    return e;
+    // branch-free (see prolong_jacobi_cell): clamped addresses, unconditional loads, selected results
+    const bool hm = F[a] - 1 >= 0 || open_lo(gf, a), hp = F[a] + 1 < nfa || open_hi(gf, a);
+    const long fm = hm ? f - stride : f, fp = hp ? f + stride : f;
+    const double vm = (double)Lf.wp[fm] * r[fm], vp = (double)Lf.wm[fp] * r[fp];
+    return r[f] + (hm ? vm : 0.0) + (hp ? vp : 0.0);
 }
 
 // coarse-grid correction fused with the first post-smoothing sweep:
@@ -411,7 +392,7 @@ __global__ __launch_bounds__(256) void k_amg_prolong_add(LevelDevT<R> Lf, GridDe
     if (tid >= Lf.g.nown) return;
     int i0, i1, i2;
     cell_ijk(Lf.g, tid, i0, i1, i2);
-    x[Lf.g.np + tid] += prolong_at(Lf, gc, ec, i0, i1, i2);
+    x[Lf.g.np + tid] += prolong_val(Lf, gc, ec, i0, i1, i2);
 }
 
 // ---- the tail: all small levels in one workgroup --------------------------------------------------------
