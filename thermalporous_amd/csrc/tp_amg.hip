@@ -12,15 +12,21 @@
 //     A_c[-a] = a_-(f) w-(g-),  A_c[+a] = a_+(f) w+(g+),
 //     A_c[d]  = a_d(f) + w+(g-) a_d(g-) + w-(g+) a_d(g+)            (cross slots),
 //     A_c[0]  = -sum(off-diagonals) + rho(f) + w+(g-) rho(g-) + w-(g+) rho(g+),  rho = row sums.
-//   V(nu,nu), damped Jacobi, dense inverse on the coarsest grid.
+//   Cycle shape: V(nu,nu) on the first amg_full_levels levels, V(coarse_pre, coarse_post) = V(0,1) below,
+//   V(0, tail_post) on the levels of <= 1024 cells; damped Jacobi; dense inverse on the coarsest grid.
 //
-// The V-cycle is launch-latency-bound below the first few levels (a level with < 10^5 cells is a
-// < 4 us kernel), so it is organised to minimise launches:
-//   * big levels: 4 fused kernels per level for V(2,2) -- [two Jacobi sweeps from a zero guess],
-//     [residual + restriction], [prolongation + first post-sweep], [last post-sweep];
-//   * all levels at or below `tail_cells` cells run inside ONE single-workgroup kernel (down-sweep,
-//     dense coarse solve, up-sweep) with workgroup barriers between phases -- for the small 2-D
-//     configurations the whole V-cycle is a single launch.
+// Below the first three levels the V-cycle is bound by the ~5 us floor of a dependent kernel, not by bytes, so it
+// is organised to minimise launches AND dependent memory round trips inside them:
+//   * levels >= 200 000 cells: separate streaming kernels (pre-smoothing pair, residual, restriction,
+//     prolongation, sweeps), XCD-aware block order, 75-80 % of HBM peak each;
+//   * smaller levels: fused kernels -- [residual + restriction] and [prolongation + first post-sweep]; the cell
+//     functions are branch-free (clamped addresses, unconditional loads, arithmetic selects) so that every load
+//     of a kernel is issued in one batch;
+//   * all levels at or below `tail_cells` cells run inside ONE single-workgroup kernel (down-sweep, dense coarse
+//     solve, up-sweep) with workgroup barriers between phases, vectors in LDS, read-only arrays touched up
+//     front -- for the small 2-D configurations the whole V-cycle is a single launch.
+// Multi-GPU: levels [0, dist_levels) are this rank's slab of the global level (halo exchange in front of every
+// kernel that reads across the slab boundary); the rest of the hierarchy is gathered and replicated.
 #include "tp_common.hpp"
 #include <algorithm>
 #include <cstdlib>

@@ -18,8 +18,11 @@
 // and D~_c^-1 backward) as [entry pair][lane][2] doubles, so that every load of the sweeps is a
 // 16-byte-per-lane, 1-KiB-per-wave fully coalesced access, each wave streams its own contiguous
 // region of HBM front to back (then back to front), and each factor byte is read exactly once per
-// application.  The chunk of step s+1 is prefetched into registers while step s computes.
-// HBM-bound: (3+4) b^2 doubles per cell plus vectors, the traffic of one block SpMV.
+// application.  The chunks of the next steps are prefetched through a ring of register buffers.
+// Traffic: (3+4) b^2 doubles per cell plus vectors, that of one block SpMV.  Measured: the solve
+// moves 4.5 TB/s but is bound by the serial recurrence, not by HBM.
+// The factorisation reads the Jacobian through k_ilu_gather, which re-orders it into the same chunk order
+// with thousands of waves (the plane layout puts neighbouring lanes n0 doubles apart).
 #include "tp_common.hpp"
 #include <cstdlib>
 
