@@ -183,6 +183,28 @@ def test_fieldsplit_cd_oracle_time_loop():
         assert np.linalg.norm(sols[0][f] - sols[1][f]) <= 1e-6*np.linalg.norm(sols[0][f])
 
 
+def test_field_output_pvd_vti(tmp_path):
+    """save=True writes pressure/temperature[/saturation_o].pvd collections of .vti pieces at t = 0 and every n_save
+    steps (thermalmodel.py:113-133, 303-322); the last piece holds the final state."""
+    import xml.etree.ElementTree as ET
+    from thermalporous_amd.output import read_vti
+    spec, u0, p, g, c = cases.c1_homogeneous(N=8, nphase=2)
+    m = TwoPhase(g, c, p, end=4.0, maxdt=1.0, small_dt_start=False, save=True, n_save=2, solver_parameters="pc_cptr",
+                 filename=str(tmp_path/"res.txt"), verbosity=False, _engine_factory=OracleEngine)
+    m.solve()
+    assert len(m.dt_vec) == 4
+    for f, name in enumerate(("pressure", "temperature", "saturation_o")):
+        coll = ET.parse(tmp_path/(name + ".pvd")).getroot().findall("Collection/DataSet")
+        assert [float(d.get("timestep")) for d in coll] == [0.0, 2.0, 4.0]          # initial + steps 2 and 4
+        nm, first = read_vti(tmp_path/coll[0].get("file"))
+        nm2, last = read_vti(tmp_path/coll[-1].get("file"))
+        assert nm == nm2 == name and first.size == last.size == 64
+        assert np.array_equal(last, m.u.dat.data_ro[f])
+        assert np.allclose(first, m.initial_condition[f] if np.ndim(m.initial_condition) > 1 else first)
+    root = ET.parse(tmp_path/"pressure_0.vti").getroot().find("ImageData")
+    assert root.get("WholeExtent") == "0 8 0 8 0 1" and root.get("Spacing").split()[0] == repr(g.Dx)
+
+
 def test_config1_time_loop_with_oracle_engine(tmp_path):
     """BASELINE config 1 (tests/test_homo_wells.py: 2 steps of dt, const-rate wells, pc cpr) end to end."""
     spec, u0, p, g, c = cases.c1_homogeneous(N=12)

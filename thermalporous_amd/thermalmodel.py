@@ -188,6 +188,9 @@ class ThermalModel:
         self.total_nits = 0
         self.nits_vec, self.lits_vec, self.dt_vec, self.timings = [], [], [], []
         self.failed_solves = 0
+        self._outfiles = None
+        if self.save:           # (:113-133) initial fields
+            self._write_fields()
         self._log("Solving time-dependent problem")
 
     def step(self):
@@ -273,7 +276,23 @@ class ThermalModel:
         current_dt = self.dt.values()[0]
         if current_dt > end-self.t and self.t < end:
             self.dt.assign(end-self.t)
+        if self.save and i % self.n_save == 0:      # (:303-322)
+            self._write_fields()
         return current_nits, current_lits
+
+    def _write_fields(self):
+        """pressure / temperature / saturation_o .pvd collections next to the results file (:113-133, :303-322).
+        Reading the state is a collective on several ranks (slabs are gathered); rank 0 writes."""
+        from .output import File
+        fields = [self.u.dat.data_ro[f] for f in range(self.nfields)]
+        if self.comm.rank != 0:
+            return
+        if self._outfiles is None:
+            d = os.path.dirname(self.filename) if self.filename else "results"
+            names = ["pressure", "temperature"] + (["saturation_o"] if self.nfields == 3 else [])
+            self._outfiles = [File(os.path.join(d or ".", n + ".pvd")) for n in names]
+        for f, out in enumerate(self._outfiles):
+            out.write(os.path.basename(out.base), fields[f], self.geo, time=self.t/DAY)
 
     def finish(self):
         """Checkpoint and results-file summary (thermalmodel.py:361-412)."""
