@@ -26,7 +26,7 @@ DEFAULT_OPTS = dict(
     amg_omega=0.8, amg_min_cells=64, amg_nu=2, amg_full_levels=3, amg_coarse_pre=0, amg_coarse_post=1, amg_tail_post=2, amg_single=False,
     schur_a11=False,
     amg_gather_cells=2000000,     # GPU multi-slab execution detail (same algebra): ignored here
-    ilu_tile=(1 << 30, 8, 8),
+    ilu_tile=None,          # None: (whole line, 8, 8) in 3-D, (whole line, 32, 1) in 2-D -- the GPU engine's default
 )
 
 
@@ -38,6 +38,8 @@ class OracleEngine:
         self.prob = Problem(spec)
         self.b = self.prob.b
         self.u = None
+        if self.opts.get("ilu_tile") is None:
+            self.opts["ilu_tile"] = (1 << 30, 32, 1) if int(spec["n"][2]) == 1 else (1 << 30, 8, 8)
         self.pc = la.TwoStagePC(self.prob, self.opts)
         self.last = {}
 
