@@ -80,6 +80,8 @@ typedef struct tp_options {
     int32_t ilu_t0;          /* tile extent along axis 0 (<= 0: the whole line) */
     int32_t amg_full_levels; /* V(nu,nu) on the first amg_full_levels levels ... */
     int32_t amg_coarse_pre, amg_coarse_post;  /* ... V(coarse_pre, coarse_post) below (coarse_post >= 1) */
+    int32_t amg_mid_skip;    /* 1: every second level between the full levels and the <= 1024-cell levels is a pure
+                                transfer level (no smoothing): two coarsening directions per smoothing level there */
     int32_t amg_tail_post;   /* post-sweeps on the levels of <= 1024 cells (they run inside one workgroup, where a
                                 sweep costs ~2 us: small grids live entirely there and want the stronger cycle) */
     int32_t amg_single;      /* 1: AMG operators/weights stored in fp32 (vectors and arithmetic stay fp64) */

@@ -185,7 +185,7 @@ class SemiAMG:
     """
 
     def __init__(self, n, strength, omega=0.8, min_cells=64, nu=1, max_levels=40, full_levels=99, coarse_pre=None,
-                 coarse_post=None, single=False, tail_post=None):
+                 coarse_post=None, single=False, tail_post=None, mid_skip=False):
         """V(nu,nu) on the first `full_levels` levels, V(coarse_pre, coarse_post) below (the coarse levels of
         the GPU cycle are launch-latency bound: dropping their pre-smoothing costs no Krylov iterations)."""
         self.n = tuple(n)
@@ -196,6 +196,8 @@ class SemiAMG:
         self.coarse_post = nu if coarse_post is None else coarse_post
         # levels of <= 1024 cells (the GPU's single-workgroup tail) may smooth more: V(coarse_pre, tail_post)
         self.tail_post = self.coarse_post if tail_post is None else tail_post
+        # every second level between the full ones and the <= 1024-cell ones is a pure transfer level
+        self.mid_skip = bool(mid_skip)
         self.sched = self._schedule(n, strength, min_cells, max_levels)
 
     @staticmethod
@@ -317,6 +319,8 @@ class SemiAMG:
             pre, post = self.nu, self.nu
         else:
             pre, post = self.coarse_pre, (self.tail_post if b.size <= 1024 else self.coarse_post)
+            if self.mid_skip and b.size > 1024 and (lvl - self.full_levels) % 2 == 1:
+                pre, post = 0, 0
         if pre == 0:
             x, r = np.zeros_like(b), b
         else:
@@ -429,7 +433,7 @@ class TwoStagePC:
         kw = dict(omega=opts["amg_omega"], min_cells=opts["amg_min_cells"], nu=opts["amg_nu"],
                   full_levels=opts.get("amg_full_levels", 99), coarse_pre=opts.get("amg_coarse_pre"),
                   coarse_post=opts.get("amg_coarse_post"), single=opts.get("amg_single", False),
-                  tail_post=opts.get("amg_tail_post"))
+                  tail_post=opts.get("amg_tail_post"), mid_skip=opts.get("amg_mid_skip", False))
 
         # coarsening schedule from the mean interior-face transmissibility per axis
         st = [float(np.mean(prob.TK[a][_lo(a)])) if n[a] > 1 else 0.0 for a in range(3)]

@@ -43,6 +43,10 @@ CASES = [
     ("c4_2ph_3d_v22", cases.c4_spe10_3d, dict(Nx=9, Ny=14, Nz=8, nphase=2), dict(pc="cptr", amg_full_levels=99)),
     ("c4_2ph_3d_v02", cases.c4_spe10_3d, dict(Nx=9, Ny=14, Nz=8, nphase=2), dict(pc="cptr", amg_full_levels=2, amg_coarse_post=2)),
     ("c4_2ph_3d_v11c", cases.c4_spe10_3d, dict(Nx=9, Ny=14, Nz=8, nphase=2), dict(pc="cptr", amg_full_levels=1, amg_coarse_pre=1, amg_coarse_post=1)),
+    # pure transfer levels (amg_mid_skip): 4608 -> 2304 (smoothed) -> 1152 (transfer only) -> 576 ... with one full level
+    ("c4_2ph_3d_midskip", cases.c4_spe10_3d, dict(Nx=16, Ny=18, Nz=16, nphase=2), dict(pc="cptr", amg_full_levels=1)),
+    ("c4_2ph_3d_midskip2", cases.c4_spe10_3d, dict(Nx=20, Ny=26, Nz=18, nphase=2), dict(pc="cptr", amg_full_levels=1, amg_single=True)),
+    ("c4_2ph_3d_nomidskip", cases.c4_spe10_3d, dict(Nx=16, Ny=18, Nz=16, nphase=2), dict(pc="cptr", amg_full_levels=1, amg_mid_skip=False)),
     # QI_temp / TI_temp: temperature AND saturation decoupled from the pressure (preconditioners.py:714-783, 810-873)
     ("c4_2ph_3d_cprQItemp", cases.c4_spe10_3d, dict(Nx=9, Ny=10, Nz=5, nphase=2), dict(pc="cpr", decoup="QI_temp")),
     ("c4_2ph_3d_cprTItemp", cases.c4_spe10_3d, dict(Nx=7, Ny=8, Nz=6, nphase=2), dict(pc="cpr", decoup="TI_temp")),

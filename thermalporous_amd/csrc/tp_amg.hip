@@ -200,7 +200,7 @@ struct LevelDevT {
     const R *invd, *wm, *wp;
     double *b, *x, *x2, *e;
     int axis;
-    int pre, post;           // smoothing sweeps of this level: V(pre, post), post >= 1
+    int pre, post;           // smoothing sweeps of this level: V(pre, post); post == 0: pure transfer level
     int pad_;
 };
 
@@ -391,6 +391,16 @@ __global__ __launch_bounds__(256) void k_amg_restrict(LevelDevT<R> Lf, GridDev g
     if (tid >= gc.nown) return;
     rc[gc.np + tid] = restrict_cell(Lf, gc, r, tid);
 }
+// x = P ec: the up-sweep of a pure transfer level
+template <class R>
+__global__ __launch_bounds__(256) void k_amg_prolong_set(LevelDevT<R> Lf, GridDev gc, const double *__restrict__ ec,
+                                                         double *__restrict__ out) {
+    const long tid = xcd_tid();
+    if (tid >= Lf.g.nown) return;
+    int i0, i1, i2;
+    cell_ijk(Lf.g, tid, i0, i1, i2);
+    out[Lf.g.np + tid] = prolong_val(Lf, gc, ec, i0, i1, i2);
+}
 template <class R>
 __global__ __launch_bounds__(256) void k_amg_prolong_add(LevelDevT<R> Lf, GridDev gc, const double *__restrict__ ec,
                                                          double *x) {
@@ -507,6 +517,15 @@ __global__ __launch_bounds__(1024) void k_amg_tail(const LevelDevT<R> *lv, int l
         // where the pre-smoothed iterate lives: x after an even number of extra sweeps, else x2; none if pre == 0
         const int extra = L.pre >= 2 ? L.pre - 2 : 0;
         const double *src = L.pre == 0 ? nullptr : ((extra % 2 == 0) ? L.x : L.x2);
+        if (L.post == 0) {                          // pure transfer level (amg_mid_skip): x = P ec
+            for (long i = t; i < L.g.nown; i += T) {
+                int i0, i1, i2;
+                cell_ijk(L.g, i, i0, i1, i2);
+                out[L.g.np + i] = prolong_val(L, gc, ec, i0, i1, i2);
+            }
+            __syncthreads();
+            continue;
+        }
         double *dst = (L.post == 1) ? out : (src == L.x ? L.x2 : L.x);
         for (long i = t; i < L.g.nown; i += T) dst[L.g.np + i] = prolong_jacobi_cell(L, gc, b, src, ec, i);
         __syncthreads();
@@ -547,6 +566,10 @@ static LevelDevT<R> dev_of(const AmgLevel *L, int level, const tp_options &o) {
     const bool small = L->g.np * (long)L->g.gn2 <= 1024;
     d.pre = full ? nu : std::max(0, o.amg_coarse_pre);
     d.post = full ? nu : std::max(1, small ? o.amg_tail_post : o.amg_coarse_post);
+    // mid levels (neither full nor small): every second one is a pure transfer level -- the hierarchy then coarsens
+    // two directions per smoothing level there, which costs no Krylov iterations (454 -> 456 on C4) and lets the
+    // cycle fuse the two transfers
+    if (o.amg_mid_skip && !full && !small && ((level - o.amg_full_levels) & 1)) { d.pre = 0; d.post = 0; }
     d.pad_ = 0;
     d.g = L->g;
     d.op.base = (R *)L->op.base;
@@ -801,6 +824,10 @@ static void vcycle_impl(tp_ctx *c, Amg *amg, const double *b, double *x) {
         double *src = xs[l];                        // its halo is still the one exchanged before the residual
         double *dst = (Ld.post == 1) ? out : (src == L->x.p ? L->x2.p : L->x.p);
         hx(l + 1, Lc->e.p);                         // distributed coarse level: parents across the boundary
+        if (Ld.post == 0) {                         // pure transfer level
+            hipLaunchKernelGGL(k_amg_prolong_set<R>, gr, bl, 0, c->stream, Ld, cv.g, ec, out);
+            continue;
+        }
         if (src && L->g.nown >= amg->fuse_below) {
             hipLaunchKernelGGL(k_amg_prolong_add<R>, gr, bl, 0, c->stream, Ld, cv.g, ec, src);
             hx(l, src);

@@ -45,7 +45,7 @@ class tp_options(C.Structure):
                 ("amg_omega", C.c_double), ("amg_nu", C.c_int32), ("amg_min_cells", C.c_int32),
                 ("ilu_t1", C.c_int32), ("ilu_t2", C.c_int32), ("ilu_t0", C.c_int32),
                 ("amg_full_levels", C.c_int32), ("amg_coarse_pre", C.c_int32), ("amg_coarse_post", C.c_int32),
-                ("amg_tail_post", C.c_int32), ("amg_single", C.c_int32), ("schur_a11", C.c_int32), ("amg_gather_cells", C.c_int32)]
+                ("amg_mid_skip", C.c_int32), ("amg_tail_post", C.c_int32), ("amg_single", C.c_int32), ("schur_a11", C.c_int32), ("amg_gather_cells", C.c_int32)]
 
 
 class tp_solve_info(C.Structure):
@@ -69,7 +69,7 @@ DEFAULT_OPTS = dict(
     pc="cpr", decoup="No",
     ksp_rtol=1e-7, ksp_atol=1e-50, ksp_max_it=200, ksp_restart=200,
     snes_rtol=1e-8, snes_atol=1e-50, snes_stol=1e-8, snes_max_it=15,
-    amg_omega=0.8, amg_min_cells=64, amg_nu=2, amg_full_levels=3, amg_coarse_pre=0, amg_coarse_post=1, amg_tail_post=2, amg_single=False,
+    amg_omega=0.8, amg_min_cells=64, amg_nu=2, amg_full_levels=3, amg_coarse_pre=0, amg_coarse_post=1, amg_mid_skip=True, amg_tail_post=2, amg_single=False,
     amg_gather_cells=2000000,
     schur_a11=False,
     ilu_tile=None,          # None: whole axis-0 lines x 8 x 8 columns (3-D), x 32 columns (2-D); see default_ilu_tile
@@ -183,7 +183,7 @@ class HipEngine:
                           o["ksp_restart"], o["snes_rtol"], o["snes_atol"], o["snes_stol"], o["snes_max_it"],
                           o["amg_omega"], o["amg_nu"], o["amg_min_cells"], int(min(t[1], 64)), int(min(t[2], 64)),
                           0 if t[0] >= (1 << 30) else int(t[0]), int(o["amg_full_levels"]), int(o["amg_coarse_pre"]),
-                          int(o["amg_coarse_post"]), int(o["amg_tail_post"]), int(bool(o["amg_single"])), int(bool(o["schur_a11"])),
+                          int(o["amg_coarse_post"]), int(bool(o["amg_mid_skip"])), int(o["amg_tail_post"]), int(bool(o["amg_single"])), int(bool(o["schur_a11"])),
                           int(o["amg_gather_cells"]))
 
     def set_options(self, **kw):

@@ -42,7 +42,7 @@ def engine_options(solver_parameters, model_name, decoup="No"):
     o = dict(DEFAULT_OPTS)
     o["decoup"] = decoup
     o["schur_a11"] = False
-    build_keys = ("amg_omega", "amg_nu", "amg_min_cells", "amg_full_levels", "amg_coarse_pre", "amg_coarse_post", "amg_tail_post", "amg_single",
+    build_keys = ("amg_omega", "amg_nu", "amg_min_cells", "amg_full_levels", "amg_coarse_pre", "amg_coarse_post", "amg_mid_skip", "amg_tail_post", "amg_single",
                   "amg_gather_cells", "ilu_tile")
     for k in build_keys:
         if k in sp:
