@@ -347,6 +347,89 @@ __device__ __forceinline__ double prolong_jacobi_cell(const LevelDevT<R> &Lf, co
     return v[0] + (double)Lf.invd[c] * (b[c] - s);
 }
 
+// ---- two levels at once: a smoothed level l followed by a pure transfer level l+1 (amg_mid_skip) ------------
+// Replicated grids only (no slab parity).  Branch-free like the single-level versions.
+// (P_l^T r) at the level-(l+1) cell (I0,I1,I2), by coordinates
+template <class R>
+__device__ __forceinline__ double restrict_at(const LevelDevT<R> &Lf, const double *__restrict__ r, int I0, int I1, int I2) {
+    const GridDev &gf = Lf.g;
+    const int a = Lf.axis;
+    const int F0 = a == 0 ? 2 * I0 : I0, F1 = a == 1 ? 2 * I1 : I1, F2 = a == 2 ? 2 * I2 : I2;
+    const int Fa = a == 0 ? F0 : (a == 1 ? F1 : F2);
+    const int nfa = a == 0 ? gf.n0 : (a == 1 ? gf.n1 : gf.n2);
+    const long stride = a == 0 ? 1 : (a == 1 ? gf.n0 : gf.np);
+    const long f = gf.np + (long)F0 + (long)gf.n0 * F1 + gf.np * F2;
+    const bool hm = Fa - 1 >= 0, hp = Fa + 1 < nfa;
+    const long fm = hm ? f - stride : f, fp = hp ? f + stride : f;
+    const double vm = (double)Lf.wp[fm] * r[fm], vp = (double)Lf.wm[fp] * r[fp];
+    return r[f] + (hm ? vm : 0.0) + (hp ? vp : 0.0);
+}
+// (P_{l+1}^T P_l^T r) at the level-(l+2) cell tid2
+template <class R>
+__device__ __forceinline__ double restrict2_cell(const LevelDevT<R> &L0, const LevelDevT<R> &L1, const GridDev &g2,
+                                                 const double *__restrict__ r, long tid2) {
+    int I[3];
+    cell_ijk(g2, tid2, I[0], I[1], I[2]);
+    const GridDev &g1 = L1.g;
+    const int a = L1.axis;
+    int M[3] = {I[0], I[1], I[2]};
+    M[a] = 2 * I[a];
+    const int n1a = a == 0 ? g1.n0 : (a == 1 ? g1.n1 : g1.n2);
+    const long stride = a == 0 ? 1 : (a == 1 ? g1.n0 : g1.np);
+    const long m = g1.np + (long)M[0] + (long)g1.n0 * M[1] + g1.np * M[2];
+    const bool hm = M[a] - 1 >= 0, hp = M[a] + 1 < n1a;
+    int Mm[3] = {M[0], M[1], M[2]}, Mp[3] = {M[0], M[1], M[2]};
+    Mm[a] -= hm ? 1 : 0;
+    Mp[a] += hp ? 1 : 0;
+    const double v0 = restrict_at(L0, r, M[0], M[1], M[2]);
+    const double vm = (double)L1.wp[hm ? m - stride : m] * restrict_at(L0, r, Mm[0], Mm[1], Mm[2]);
+    const double vp = (double)L1.wm[hp ? m + stride : m] * restrict_at(L0, r, Mp[0], Mp[1], Mp[2]);
+    return v0 + (hm ? vm : 0.0) + (hp ? vp : 0.0);
+}
+// (P_l P_{l+1} e2) at the level-l cell (F0,F1,F2) (clamped coordinates)
+template <class R>
+__device__ __forceinline__ double prolong2_val(const LevelDevT<R> &L0, const LevelDevT<R> &L1, const GridDev &g2,
+                                               const double *__restrict__ e2, int F0, int F1, int F2) {
+    const GridDev &g = L0.g, &g1 = L1.g;
+    const int a = L0.axis;
+    const int Fa = a == 0 ? F0 : (a == 1 ? F1 : F2);
+    const int Ia = Fa >> 1;
+    const bool isF = Fa & 1;
+    const int n1a = a == 0 ? g1.n0 : (a == 1 ? g1.n1 : g1.n2);
+    const bool hasR = isF && (Ia + 1 < n1a);
+    const int I0 = a == 0 ? Ia : F0, I1 = a == 1 ? Ia : F1, I2 = a == 2 ? Ia : F2;
+    const int J0 = I0 + (a == 0 && hasR), J1 = I1 + (a == 1 && hasR), J2 = I2 + (a == 2 && hasR);
+    const long cf = g.np + (long)F0 + (long)g.n0 * F1 + g.np * F2;
+    const double wm = (double)L0.wm[cf], wp = (double)L0.wp[cf];
+    const double v0 = prolong_val(L1, g2, e2, I0, I1, I2), v1 = prolong_val(L1, g2, e2, J0, J1, J2);
+    return isF ? wm * v0 + (hasR ? wp * v1 : 0.0) : v0;
+}
+// x' = P_l P_{l+1} e2 ;  out = x' + invd (b - A x')     (level l has no pre-smoothing)
+template <class R>
+__device__ __forceinline__ double prolong2_jacobi_cell(const LevelDevT<R> &L0, const LevelDevT<R> &L1, const GridDev &g2,
+                                                       const double *__restrict__ b, const double *__restrict__ e2,
+                                                       long tid) {
+    const GridDev &g = L0.g;
+    int i0, i1, i2;
+    cell_ijk(g, tid, i0, i1, i2);
+    const long c = g.np + tid;
+    const int m0 = max(i0 - 1, 0), p0 = min(i0 + 1, g.n0 - 1);
+    const int m1 = max(i1 - 1, 0), p1 = min(i1 + 1, g.n1 - 1);
+    const int m2 = max(i2 - 1, 0), p2 = min(i2 + 1, g.n2 - 1);
+    double v[7];
+    v[0] = prolong2_val(L0, L1, g2, e2, i0, i1, i2);
+    v[1] = prolong2_val(L0, L1, g2, e2, m0, i1, i2);
+    v[2] = prolong2_val(L0, L1, g2, e2, p0, i1, i2);
+    v[3] = prolong2_val(L0, L1, g2, e2, i0, m1, i2);
+    v[4] = prolong2_val(L0, L1, g2, e2, i0, p1, i2);
+    v[5] = prolong2_val(L0, L1, g2, e2, i0, i1, m2);
+    v[6] = prolong2_val(L0, L1, g2, e2, i0, i1, p2);
+    double s = 0.0;
+#pragma unroll
+    for (int k = 0; k < 7; ++k) s += (double)L0.op.slot(k)[c] * v[k];
+    return v[0] + (double)L0.invd[c] * (b[c] - s);
+}
+
 // ---- per-level kernels (big levels) -----------------------------------------------------------------
 template <class R>
 __global__ __launch_bounds__(256) void k_amg_pre(LevelDevT<R> L, const double *b, int two, double *out) {
@@ -374,6 +457,21 @@ __global__ __launch_bounds__(256) void k_amg_prolong_jacobi(LevelDevT<R> Lf, Gri
     const long tid = xcd_tid();
     if (tid >= Lf.g.nown) return;
     out[Lf.g.np + tid] = prolong_jacobi_cell(Lf, gc, b, x, ec, tid);
+}
+
+template <class R>
+__global__ __launch_bounds__(256) void k_amg_restrict2(LevelDevT<R> L0, LevelDevT<R> L1, GridDev g2, const double *r,
+                                                       double *rc) {
+    const long tid = xcd_tid();
+    if (tid >= g2.nown) return;
+    rc[g2.np + tid] = restrict2_cell(L0, L1, g2, r, tid);
+}
+template <class R>
+__global__ __launch_bounds__(256) void k_amg_prolong2_jacobi(LevelDevT<R> L0, LevelDevT<R> L1, GridDev g2, const double *b,
+                                                             const double *e2, double *out) {
+    const long tid = xcd_tid();
+    if (tid >= L0.g.nown) return;
+    out[L0.g.np + tid] = prolong2_jacobi_cell(L0, L1, g2, b, e2, tid);
 }
 
 // unfused variants for the top levels, where the fused kernels are issue-bound rather than HBM-bound
@@ -762,6 +860,13 @@ static void vcycle_impl(tp_ctx *c, Amg *amg, const double *b, double *x) {
     const int nlev = (int)amg->lv.size(), lt = amg->tail_level, lg = amg->dist_levels;
     const dim3 bl(256);
     std::vector<double *> xs(nlev, nullptr);       // pre-smoothed iterate of each big level (null: none)
+    // level l (smoothed, no pre-sweeps) + level l+1 (pure transfer): both transfers in one launch each way
+    static const bool pair_on = !(getenv("TP_AMG_PAIR") && atoi(getenv("TP_AMG_PAIR")) == 0);
+    auto paired = [&](int l) {
+        if (!pair_on || l < lg || l + 2 > lt || amg->lv[l]->g.nown >= amg->fuse_below) return false;
+        const LevelDevT<R> A = dev_of<R>(amg->lv[l], l, c->opt), B = dev_of<R>(amg->lv[l + 1], l + 1, c->opt);
+        return A.pre == 0 && A.post >= 1 && B.pre == 0 && B.post == 0;
+    };
     auto hx = [&](int l, const double *v) {        // halo exchange of a level-l vector (no-op below lg)
         if (l < lg) halo_exchange(c, amg->lv[l]->g, const_cast<double *>(v), 1, 0);
     };
@@ -775,6 +880,13 @@ static void vcycle_impl(tp_ctx *c, Amg *amg, const double *b, double *x) {
         double *bc = Lc->b.p + cv.off;
         const dim3 gr = xcd_grid(L->g.nown);
         const bool slab_axis = l < lg && L->axis == 2;      // the transfer itself crosses the slab boundary
+        if (paired(l)) {
+            AmgLevel *L2 = amg->lv[l + 2];
+            hipLaunchKernelGGL(k_amg_restrict2<R>, xcd_grid(L2->g.nown), bl, 0, c->stream, Ld,
+                               dev_of<R>(amg->lv[l + 1], l + 1, c->opt), L2->g, bl_, L2->b.p);
+            ++l;                                    // level l+1 has nothing else to do on the way down
+            continue;
+        }
         if (Ld.pre == 0) {                          // V(0,post): residual = b
             if (slab_axis) hx(l, bl_);
             hipLaunchKernelGGL(k_amg_restrict<R>, xcd_grid(cv.g.nown), bl, 0, c->stream, Ld, cv.g, bl_, bc);
@@ -823,6 +935,18 @@ static void vcycle_impl(tp_ctx *c, Amg *amg, const double *b, double *x) {
         const dim3 gr = xcd_grid(L->g.nown);
         double *src = xs[l];                        // its halo is still the one exchanged before the residual
         double *dst = (Ld.post == 1) ? out : (src == L->x.p ? L->x2.p : L->x.p);
+        if (l >= 1 && paired(l - 1)) continue;      // transfer-only level folded into its parent's launch
+        if (paired(l)) {
+            AmgLevel *L2 = amg->lv[l + 2];
+            hipLaunchKernelGGL(k_amg_prolong2_jacobi<R>, gr, bl, 0, c->stream, Ld, dev_of<R>(Lc, l + 1, c->opt), L2->g, bl_,
+                               (const double *)L2->e.p, dst);
+            for (int k = 1; k < Ld.post; ++k) {
+                src = dst;
+                dst = (k == Ld.post - 1) ? out : (src == L->x.p ? L->x2.p : L->x.p);
+                hipLaunchKernelGGL(k_amg_jacobi<R>, gr, bl, 0, c->stream, Ld, bl_, (const double *)src, dst);
+            }
+            continue;
+        }
         hx(l + 1, Lc->e.p);                         // distributed coarse level: parents across the boundary
         if (Ld.post == 0) {                         // pure transfer level
             hipLaunchKernelGGL(k_amg_prolong_set<R>, gr, bl, 0, c->stream, Ld, cv.g, ec, out);
