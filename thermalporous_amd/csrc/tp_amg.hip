@@ -13,7 +13,8 @@
 //     A_c[d]  = a_d(f) + w+(g-) a_d(g-) + w-(g+) a_d(g+)            (cross slots),
 //     A_c[0]  = -sum(off-diagonals) + rho(f) + w+(g-) rho(g-) + w-(g+) rho(g+),  rho = row sums.
 //   Cycle shape: V(nu,nu) on the first amg_full_levels levels, V(coarse_pre, coarse_post) = V(0,1) below,
-//   V(0, tail_post) on the levels of <= 1024 cells; damped Jacobi; dense inverse on the coarsest grid.
+//   V(0, tail_post) on the levels of <= 1024 cells; every second level in between is a pure transfer level
+//   (amg_mid_skip) folded into its parent's launches; damped Jacobi; dense inverse on the coarsest grid.
 //
 // Below the first three levels the V-cycle is bound by the ~5 us floor of a dependent kernel, not by bytes, so it
 // is organised to minimise launches AND dependent memory round trips inside them:
