@@ -243,7 +243,8 @@ void stage1_rhs(tp_ctx *c, const double *x, int q, double *out);                
 // ILU
 void ilu_setup(tp_ctx *c);
 void ilu_factor(tp_ctx *c);
-void ilu_solve(tp_ctx *c, const double *r, double *x, const double *addto);             // x = addto + M^-1 r
+// x = addto + M^-1 r ; only the first nadd fields of addto are read, the others count as zero (< 0: all fields)
+void ilu_solve(tp_ctx *c, const double *r, double *x, const double *addto, int nadd = -1);
 // AMG
 void amg_build(tp_ctx *c, Amg *&amg, const GridDev &g0, const double strength[3]);
 void amg_setup(tp_ctx *c, Amg *amg, const Stencil &A0);
@@ -259,7 +260,7 @@ void slab_of(const tp_ctx *c, int rank, int &lo, int &hi);
 void gather_slabs(tp_ctx *c, const double *local, long lstride, double *global, long gstride, int nplanes);
 // solver
 void pc_setup(tp_ctx *c);
-void stage1_apply(tp_ctx *c, const double *x, double *y);
+void stage1_apply(tp_ctx *c, const double *x, double *y, bool zero_secondary = true);
 void pc_apply(tp_ctx *c, const double *x, double *y);
 int fgmres(tp_ctx *c, const double *b, double *x, int *its, double *rnorm);
 void newton(tp_ctx *c, tp_solve_info *info);

@@ -308,7 +308,8 @@ __device__ __forceinline__ double chunk_get(const double2 (&v)[NP], int e) {
 template <int B, bool DEPTH2>
 __global__ __launch_bounds__(64) void k_ilu_solve(IluGeom G, const double *__restrict__ fwd,
                                                   const double *__restrict__ bwd, const double *__restrict__ rhs,
-                                                  double *__restrict__ ytmp, double *x, const double *addto) {
+                                                  double *__restrict__ ytmp, double *x, const double *addto,
+                                                  int nadd) {
     using L = IluLayout<B>;
     const int tile = blockIdx.x, lane = threadIdx.x;
     const long nt = G.g.ntot;
@@ -384,7 +385,8 @@ __global__ __launch_bounds__(64) void k_ilu_solve(IluGeom G, const double *__res
             load_chunk<L::PB>(bwd + (chunk0 + step) * (L::PB * 128), lane, buf[k]);
             load_chunk<L::PY>(ytmp + (chunk0 + step) * (L::PY * 128), lane, ybuf[k]);
 #pragma unroll
-            for (int r = 0; r < B; ++r) aa[k][r] = (okk[k] && addto) ? addto[(long)r * nt + c] : 0.0;
+            for (int r = 0; r < B; ++r)      // fields >= nadd of addto are taken as zero (never read)
+                aa[k][r] = (okk[k] && addto && r < nadd) ? addto[(long)r * nt + c] : 0.0;
         };
         auto step = [&](int k) {
             double xn[3][B], xv[B];
@@ -492,13 +494,14 @@ void ilu_factor(tp_ctx *c) {
     TP_HIP(hipGetLastError());
 }
 
-void ilu_solve(tp_ctx *c, const double *r, double *x, const double *addto) {
+void ilu_solve(tp_ctx *c, const double *r, double *x, const double *addto, int nadd) {
+    if (nadd < 0) nadd = c->b;
     TP_REQUIRE(c->ilu.slots > 0, "ILU not factored");
     const IluGeom G = geom_of(c);
     static const bool deep = !(getenv("TP_ILU_DEPTH") && atoi(getenv("TP_ILU_DEPTH")) == 1);
 #define TP_ILU_LAUNCH(BB, DD)                                                                                  \
     hipLaunchKernelGGL((k_ilu_solve<BB, DD>), dim3(c->ilu.ntiles), dim3(64), 0, c->stream, G, c->ilu.fwd.p, \
-                       c->ilu.bwd.p, r, c->ilu.ytmp.p, x, addto)
+                       c->ilu.bwd.p, r, c->ilu.ytmp.p, x, addto, nadd)
     if (c->b == 3) { if (deep) TP_ILU_LAUNCH(3, true); else TP_ILU_LAUNCH(3, false); }
     else           { if (deep) TP_ILU_LAUNCH(2, true); else TP_ILU_LAUNCH(2, false); }
 #undef TP_ILU_LAUNCH

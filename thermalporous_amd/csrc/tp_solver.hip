@@ -154,14 +154,15 @@ void pc_setup(tp_ctx *c) {
 }
 
 // y = B1 x :  CPRStage1PC.apply (preconditioners.py:881-903) / CPTRStage1PC.apply (:1550-1567)
-void stage1_apply(tp_ctx *c, const double *x, double *y) {
+void stage1_apply(tp_ctx *c, const double *x, double *y, bool zero_secondary) {
     const GridDev &g = c->g;
     const long nt = g.ntot;
     ensure_work(c);
     double *r0 = c->w3.p, *r1 = c->w3.p + nt, *t = c->w3.p + 2 * nt;   // w3 has >= 3 planes
     // y_s = 0 for the non-primary fields (:902-903, :1566-1567)
     const int npri = npri_of(c->opt);
-    for (int f = npri; f < c->b; ++f) vec_zero(c, y + (long)f * nt, nt);
+    if (zero_secondary)
+        for (int f = npri; f < c->b; ++f) vec_zero(c, y + (long)f * nt, nt);
     if (c->opt.decoup == 0 && !c->dist) {
         // decoupling "No" (pc_cptr, pc_cpr, pc_fieldsplit_cd presets): the stage-1 right-hand sides ARE the
         // primary fields of x -- no copy (multi-GPU keeps the copy: the V-cycle's exchange writes b's halos)
@@ -215,11 +216,12 @@ void stage1_apply(tp_ctx *c, const double *x, double *y) {
 // composite multiplicative: y = B1 x ; r = x - J y ; y += B2 r
 static void pc_apply_body(tp_ctx *c, const double *x, double *y) {
     const int npri = npri_of(c->opt);
-    stage1_apply(c, x, y);       // multi-GPU, replicated stage 1: y comes back with live halo planes
+    // (y's secondary fields are left untouched: the second stage below never reads them and overwrites them)
+    stage1_apply(c, x, y, false);                 // multi-GPU, replicated stage 1: y comes back with live halo planes
     if (c->dist && c->amg_p->dist_levels > 0) halo_exchange(c, c->g, y, npri, c->g.ntot);
     if (c->opt.pc_kind == 2) return;                          // pc_fieldsplit_cd: the Schur stage IS the preconditioner
     resid_block_cols(c, c->J.p, x, y, npri, c->w1.p);        // secondary fields of y are zero
-    ilu_solve(c, c->w1.p, y, y);                             // y = y + M^-1 r
+    ilu_solve(c, c->w1.p, y, y, npri);                       // y = y + M^-1 r  (y's secondary fields are zero: not read)
 }
 
 // One preconditioner application is ~100 short kernels (the V-cycles' coarse levels); issued eagerly
