@@ -1,17 +1,28 @@
 #!/usr/bin/env python3
-"""bench.py -- Newton steps/s (+ FGMRES its/s) of the hot path on BASELINE config 4:
+"""bench.py -- Newton steps/s (+ FGMRES its/s) of the hot path; default = BASELINE config 4:
 two-phase 3-D SPE10-like 60x220x85 box, wells + heaters, pc_cptr (CPTR: fieldsplit-Schur stage 1 with
 AMG V-cycles on App and S~, block-Jacobi block-ILU(0) stage 2) inside FGMRES inside Newton.
 
-    python bench.py --gpus N --steps K --warmup W
+    python bench.py --gpus N --steps K --warmup W [--config c1|c2|c3|c4|c5slab]
     python -m torch.distributed.run --nnodes=1 --nproc-per-node N ... bench.py --gpus N ...
 
 A "step" is one time step of the reference's time loop = one ``solver.solve()`` (one Newton solve with
 its linear solves) + the loop's dt policy (thermalporous_amd/thermalmodel.py:step).  All inputs are
 synthetic (the SPE10 .dat files are not shipped with the reference) and resident in HBM before the
-timed region.  N > 1: the fixed 60x220x85 problem is cut into N slabs along y ("strong" scaling).
-Rank 0 prints ONE JSON line with the metric, a roofline object for the block SpMV kernel and the CPU
-baseline (the numpy oracle, timed on a bounded sample; never the thing measured).
+timed region.
+
+Time-stepping regime ("time steps of 0.1 day" on config 4).  From the uniform initial state a
+cold 0.1-day step does not converge with the reference's `basic` line search, so the run first SPINS UP with
+the reference's own dt ramp (dt = maxdt*2^-10, growing by the SPE10 rule of thermalmodel.py:337-345) until dt
+has reached maxdt -- untimed, not counted in W -- then does W warm-up steps and K timed steps, all at
+dt = maxdt unless the reference's failure policy cuts dt (reported: dt range, failed solves).  The rate seen
+during the spin-up ramp is reported as a secondary field (``ramp``).
+
+N > 1: the fixed box is cut into N slabs along the internal slab axis ("strong" scaling).
+Rank 0 prints ONE JSON line: the metric, a ``roofline`` object for the dominant single kernel of a Krylov
+iteration (the block-ILU(0) solve) with the block SpMV and the other streaming kernels beside it, and the
+``cpu_baseline`` (oracle/cport: the C++/OpenMP restatement of the same algorithm, timed on this box's host
+cores from the SAME state and dt as the first timed step; never the thing measured).
 """
 import argparse
 import json
@@ -26,57 +37,132 @@ sys.path.insert(0, ROOT)
 
 HBM_PEAK_GBS = 8000.0          # MI355X_MICROARCH.md: HBM3E 8 TB/s spec
 SPMV_BYTES_PER_CELL = {(3, 7): 584, (3, 5): 432, (2, 7): 292, (2, 5): 216}
+# algorithmic bytes per cell of the other streaming kernels, keyed like SPMV_BYTES_PER_CELL:
+#   ILU(0) solve = SpMV;  assembly = 3b*8 + 8 + d*8 + 8 + s*b*b*8;  ILU factor = 2*s*b*b*8 + idx
+ASM_BYTES_PER_CELL = {(3, 7): 616, (3, 5): 464, (2, 7): 296, (2, 5): 232}
+FACTOR_BYTES_PER_CELL = {(3, 7): 1040, (3, 5): 744, (2, 7): 480, (2, 5): 344}
+
+CONFIGS = {
+    # name: (description, default grid)
+    "c1": ("BASELINE config 1: single-phase 2D homogeneous NxN (tests/test_homo_wells.py), const-rate wells, pc_cpr, "
+           "dt 1 day", (400, 400, 1)),
+    "c2": ("BASELINE config 2: single-phase 2D SPE10-like 60x220 layer, Peaceman wells, pc_cpr, maxdt 1 day", (60, 220, 1)),
+    "c3": ("BASELINE config 3: two-phase 2D SPE10-like 60x220 layer, Peaceman wells, pc_cptr, maxdt 1 day", (60, 220, 1)),
+    "c4": ("BASELINE config 4: two-phase 3D SPE10-like 60x220x85, wells+heaters, pc_cptr, maxdt 0.1 day", (60, 220, 85)),
+    "c5slab": ("BASELINE config 5, ONE of its 8 slabs: two-phase 3D 240x110x340 (60x220x85 field upsampled x4), "
+               "21+21 'large' wells, pc_cptr, maxdt 0.1 day", (240, 110, 340)),
+}
 
 
-def build_case(name, Nxyz=None, refine=1):
-    """BASELINE configs on synthetic data."""
+def build_case(name, Nxyz=None):
+    """BASELINE configs on synthetic data.  Returns (params, geo, case, model class, model kwargs)."""
     from thermalporous_amd.physicalparameters import PhysicalParameters
+    params = PhysicalParameters()
+    Nx, Ny, Nz = Nxyz or CONFIGS[name][1]
+    if name == "c1":
+        from thermalporous_amd.homogeneousgeo import HomogeneousGeo
+        from thermalporous_amd.wellcase import WellCase
+        from thermalporous_amd.singlephase import SinglePhase
+        params.rate = 1e-6          # tests/test_homo_wells.py:10-12 of the reference
+        params.T_prod = 320.0
+        geo = HomogeneousGeo(Nx, Ny, params, 20.0, 20.0)
+        case = WellCase(params, geo, well_case="test0", constant_rate=True)
+        return params, geo, case, SinglePhase, dict(maxdt=1.0, small_dt_start=False, solver_parameters="pc_cpr")
+    if name in ("c2", "c3"):
+        from thermalporous_amd.SPE10model import SPE10Model
+        from thermalporous_amd.wellcase import WellCase
+        two = name == "c3"
+        params.rate = 2e-4 if two else 1e-3      # tests_twophase/test_60x120_wells_default.py:8-9 / tests/..._default.py:8
+        if two:
+            params.S_o = 0.9
+        geo = SPE10Model(Nx, Ny, params)
+        L, Ly = geo.Length, geo.Length_y
+        case = WellCase(params, geo, prod_points=[[140.0/365.76*L, 210.0/670.56*Ly]],
+                        inj_points=[[265.0/365.76*L, 260.0/670.56*Ly]])
+        if two:
+            from thermalporous_amd.twophase import TwoPhase
+            return params, geo, case, TwoPhase, dict(maxdt=1.0, small_dt_start=True, solver_parameters="pc_cptr")
+        from thermalporous_amd.singlephase import SinglePhase
+        return params, geo, case, SinglePhase, dict(maxdt=1.0, small_dt_start=True, solver_parameters="pc_cpr")
     from thermalporous_amd.SPE10model3D import SPE10Model3D
     from thermalporous_amd.wellheatercase import WellHeaterCase
-    params = PhysicalParameters()
+    from thermalporous_amd.twophase import TwoPhase
     params.rate = 2e-4          # tests_twophase/test_60x120_wells_default.py:8-9 of the reference
     params.S_o = 0.9
     params.T_inj = 373.15
     if name == "c4":
-        Nx, Ny, Nz = Nxyz or (60, 220, 85)
+        geo = SPE10Model3D(Nx, Ny, Nz, params)
+        L, Ly, Lz = geo.Length, geo.Length_y, geo.Length_z
+        # SPE10 well (x,y) positions (wellcase.py:30-36), producer low / injector high in the column
+        prod = [[140.0/365.76*L, 210.0/670.56*Ly, 0.2*Lz]]
+        inj = [[265.0/365.76*L, 260.0/670.56*Ly, 0.8*Lz]]
+        case = WellHeaterCase(params, geo, prod_points=prod, inj_points=inj)
+    elif name == "c5slab":
+        geo = SPE10Model3D(Nx, Ny, Nz, params, refine=4)      # cells 1/4 of the SPE10 size in every direction
+        case = WellHeaterCase(params, geo, well_case="large")  # wellcase.py:58-64: 21 + 21 wells (and heaters)
     else:
         raise ValueError(name)
-    geo = SPE10Model3D(Nx, Ny, Nz, params, refine=refine)    # refine r: the 60x220x85 field upsampled r-fold (BASELINE config 5: r=4)
-    L, Ly, Lz = geo.Length, geo.Length_y, geo.Length_z
-    # SPE10 well (x,y) positions (wellcase.py:30-36), producer low / injector high in the column
-    prod = [[140.0/365.76*L, 210.0/670.56*Ly, 0.2*Lz]]
-    inj = [[265.0/365.76*L, 260.0/670.56*Ly, 0.8*Lz]]
-    case = WellHeaterCase(params, geo, prod_points=prod, inj_points=inj)
-    return params, geo, case
+    return params, geo, case, TwoPhase, dict(maxdt=0.1, small_dt_start=True, solver_parameters="pc_cptr")
 
 
-def make_model(name, engine_factory=None, Nxyz=None, maxdt=0.1, refine=1):
-    from thermalporous_amd.twophase import TwoPhase
-    params, geo, case = build_case(name, Nxyz, refine)
-    return TwoPhase(geo, case, params, end=1e9, maxdt=maxdt, small_dt_start=True, solver_parameters="pc_cptr",
-                    filename=None, verbosity=False, _engine_factory=engine_factory)
+def make_model(name, engine_factory=None, Nxyz=None, **over):
+    params, geo, case, cls, kw = build_case(name, Nxyz)
+    kw.update(over)
+    return cls(geo, case, params, end=1e9, filename=None, verbosity=False, _engine_factory=engine_factory, **kw)
 
 
-def cpu_baseline(steps=1):
-    """The numpy oracle (a "port" of the reference algorithm) on a bounded sample: the first time steps of
-    the same case on a 30x110x43 sub-box (1/8 of the cells), one core.  Newton steps/s on the full box is
-    estimated as the sample rate divided by 8 (cost is linear in cells); both numbers are reported."""
-    from oracle.engine import OracleEngine
-    frac = 8.0
-    m = make_model("c4", engine_factory=OracleEngine, Nxyz=(30, 110, 43))
-    m.start()
+def spin_up(model, cap):
+    """The reference's own dt ramp from maxdt*dt_init_fact up to maxdt (untimed initialisation of the state)."""
+    maxdt_s = model.maxdt*86400.0
+    n = 0
     t0 = time.perf_counter()
-    nits = lits = 0
-    for _ in range(steps):
-        n, l = m.step()
-        nits += n
-        lits += l
-    el = time.perf_counter() - t0
-    return {"value": nits/el/frac, "unit": "Newton steps/s", "cores": 1, "kind": "port",
-            "sample": "numpy oracle, first %d time step(s) of the same case on a 30x110x43 sub-box (1/8 of the cells): "
-                      "%.3f Newton steps/s, %.2f FGMRES its/s measured in %.1f s; value = measured/8 (linear-in-cells "
-                      "estimate for 60x220x85)" % (steps, nits/el, lits/el, el),
-            "fgmres_its_per_s": lits/el/frac}
+    while float(model.dt) < maxdt_s*(1.0 - 1e-12) and n < cap:
+        model.step()
+        n += 1
+    return n, time.perf_counter() - t0
+
+
+def cpu_baseline(name, Nxyz, u, u_old, dt, budget_s=25.0):
+    """oracle/cport (C++/OpenMP restatement of the same algorithm; test infrastructure, never the product) on the
+    GPU box's host cores: the Newton solve of the FIRST timed time step -- same state, same old state, same dt,
+    same tolerances -- cut off after `budget_s` seconds of work per leg (whole Krylov iterations).  Two legs:
+    1 thread and all cores."""
+    from oracle import cport
+    m = make_model(name, engine_factory=cport.CPortEngine, Nxyz=Nxyz)
+    eng = m.engine
+    out = {}
+    ncores = os.cpu_count() or 1
+    for label, nthreads in (("t1", 1), ("all", ncores)):
+        eng.set_threads(nthreads)
+        eng.set_state(u)
+        eng.set_old(u_old)
+        eng.set_dt(dt)
+        r = eng.newton_solve(budget_s=budget_s)
+        out[label] = dict(threads=nthreads, seconds=r["seconds"], newton_its=r["nits_done"], fgmres_its=r["lits"],
+                          newton_per_s=r["nits_done"]/r["seconds"], fgmres_per_s=r["lits"]/r["seconds"],
+                          complete=bool(r["complete"]))
+    best = out["all"]
+    return {"value": best["newton_per_s"], "unit": "Newton steps/s", "cores": best["threads"], "kind": "port",
+            "fgmres_its_per_s": best["fgmres_per_s"],
+            "one_thread": {"value": out["t1"]["newton_per_s"], "fgmres_its_per_s": out["t1"]["fgmres_per_s"]},
+            "cpu_model": _cpu_model(),
+            "sample": "oracle/cport (C++/OpenMP restatement of the reference algorithm, f64) on the same case, from the "
+                      "state at the start of the timed region, dt %.4g d: %d-thread leg %.1f s (%.2f Newton its, %d FGMRES "
+                      "its%s), 1-thread leg %.1f s (%.2f Newton its, %d FGMRES its%s); Newton its counted fractionally "
+                      "by Krylov iterations done when the time budget cut a linear solve"
+                      % (dt/86400.0, best["threads"], best["seconds"], best["newton_its"], best["fgmres_its"],
+                         "" if best["complete"] else ", cut by budget", out["t1"]["seconds"], out["t1"]["newton_its"],
+                         out["t1"]["fgmres_its"], "" if out["t1"]["complete"] else ", cut by budget")}
+
+
+def _cpu_model():
+    try:
+        for line in open("/proc/cpuinfo"):
+            if line.startswith("model name"):
+                return line.split(":", 1)[1].strip()
+    except OSError:
+        pass
+    return "unknown"
 
 
 def main():
@@ -84,8 +170,10 @@ def main():
     ap.add_argument("--gpus", type=int, default=1)
     ap.add_argument("--steps", type=int, default=8)
     ap.add_argument("--warmup", type=int, default=2)
-    ap.add_argument("--config", default="c4")
+    ap.add_argument("--config", default="c4", choices=sorted(CONFIGS))
     ap.add_argument("--no-cpu-baseline", action="store_true")
+    ap.add_argument("--cpu-budget", type=float, default=25.0, help="seconds of CPU work per cpu_baseline leg")
+    ap.add_argument("--spinup-cap", type=int, default=80, help="max time steps of the untimed dt ramp")
     ap.add_argument("--grid", type=int, nargs=3, default=None, help="override Nx Ny Nz (development only)")
     args = ap.parse_args()
 
@@ -101,12 +189,26 @@ def main():
     if not torch.cuda.is_available():
         raise SystemExit("bench.py needs an MI355X: the hot path has no CPU fallback")
 
-    model = make_model(args.config, Nxyz=tuple(args.grid) if args.grid else None)
+    Nxyz = tuple(args.grid) if args.grid else None
+    model = make_model(args.config, Nxyz=Nxyz)
     eng = model.engine
     model.start()
+    # ---- spin-up: the reference's dt ramp, untimed ------------------------------------------------------
+    n_spin, t_spin = spin_up(model, args.spinup_cap)
+    ramp = {"steps": n_spin, "newton_its": model.total_nits, "fgmres_its": model.total_lits,
+            "failed_solves": model.failed_solves, "solve_seconds": float(sum(model.timings)),
+            "newton_per_s": model.total_nits/max(sum(model.timings), 1e-300),
+            "fgmres_per_s": model.total_lits/max(sum(model.timings), 1e-300),
+            "dt_days": [model.dt_vec[0]/86400.0, model.dt_vec[-1]/86400.0] if model.dt_vec else None}
     for _ in range(args.warmup):
         model.step()
-    n0, l0, f0 = model.total_nits, model.total_lits, model.failed_solves
+    n0, l0, f0, s0 = model.total_nits, model.total_lits, model.failed_solves, len(model.dt_vec)
+    # state at the start of the timed region, for the CPU leg (same state, same dt)
+    want_cpu = (not args.no_cpu_baseline) and world == 1
+    if want_cpu:
+        u_start = eng.get_state().copy()
+        uold_start = eng.get_old_state().copy()
+        dt_start = float(model.dt)
     torch.cuda.synchronize()
     parallel.barrier()
     t0 = time.perf_counter()
@@ -120,37 +222,47 @@ def main():
         torch.distributed.all_reduce(t, op=torch.distributed.ReduceOp.MAX)
         el = float(t.item())
     nits, lits = model.total_nits - n0, model.total_lits - l0
+    dts = np.array(model.dt_vec[s0:])/86400.0
 
-    # roofline of the dominant streaming kernel of one Krylov iteration: the 7-point 3x3-block SpMV
+    # ---- per-kernel HIP-event timings on the library's stream, on the final Jacobian of the timed region ------
     eng._ck(eng.lib.tp_jacobian(eng.ctx))
     eng.pc_setup()
     ncell_local = eng.n[0]*eng.n[1]*eng.n[2]
-    ms = eng.time_kernel(0, 50)
-    bpc = SPMV_BYTES_PER_CELL[(eng.b, 7 if eng.gn[2] > 1 else 5)]
-    achieved = bpc*ncell_local/(ms*1e-3)/1e9
-    extra = {nm: eng.time_kernel(w, 20) for w, nm in ((1, "ilu_solve_ms"), (2, "amg_vcycle_ms"), (3, "assembly_ms"),
-                                                       (4, "pc_apply_ms"), (5, "pc_setup_ms"), (6, "ilu_factor_ms"))}
-    # the other streaming kernels against the same roofline (algorithmic bytes per cell: SURVEY.md 8d)
-    others = {}
-    if eng.b == 3 and eng.gn[2] > 1:
-        for nm, key, bytes_per_cell in (("ilu0_solve", "ilu_solve_ms", 584), ("assembly_residual_jacobian", "assembly_ms", 616),
-                                        ("ilu0_factor(gather+factor)", "ilu_factor_ms", 1040)):
-            gbs = bytes_per_cell*ncell_local/(extra[key]*1e-3)/1e9
-            others[nm] = {"bytes_per_cell": bytes_per_cell, "avg_ms": extra[key], "achieved_GBs": gbs, "frac": gbs/HBM_PEAK_GBS}
+    key = (eng.b, 7 if eng.gn[2] > 1 else 5)
+    km = {nm: eng.time_kernel(w, reps) for w, nm, reps in ((0, "spmv_ms", 50), (1, "ilu_solve_ms", 50), (2, "amg_vcycle_ms", 20),
+                                                           (3, "assembly_ms", 20), (4, "pc_apply_ms", 20), (5, "pc_setup_ms", 20),
+                                                           (6, "ilu_factor_ms", 20))}
+
+    def line(bytes_per_cell, ms):
+        gbs = bytes_per_cell*ncell_local/(ms*1e-3)/1e9
+        return {"bytes_per_cell": bytes_per_cell, "avg_ms": ms, "achieved_GBs": gbs, "frac": gbs/HBM_PEAK_GBS}
+    others = {"spmv_block": line(SPMV_BYTES_PER_CELL[key], km["spmv_ms"]),
+              "assembly_residual_jacobian": line(ASM_BYTES_PER_CELL[key], km["assembly_ms"]),
+              "ilu0_factor": line(FACTOR_BYTES_PER_CELL[key], km["ilu_factor_ms"])}
     if rank != 0:
         return
-    # HBM traffic per launch of the same kernel from the PMC passes (rocprofv3 --pmc FETCH_SIZE / WRITE_SIZE in
-    # separate runs, gfx950 correction applied; see profiles/r01_pmc_traffic.json "how"): only quoted when the
-    # committed profile is of this very launch shape
+    ilu = line(SPMV_BYTES_PER_CELL[key], km["ilu_solve_ms"])
+    # one whole Krylov iteration (pc_apply + SpMV + Gram-Schmidt) as achieved algorithmic bytes/s: for the small 2-D
+    # configurations, which are latency bound, this -- not a kernel's roofline fraction -- is the honest figure
+    it_ms = 1e3*el/max(lits, 1)
+    # HBM traffic per launch from the PMC passes (rocprofv3 --pmc FETCH_SIZE / WRITE_SIZE in separate runs, gfx950
+    # correction applied; profiles/r02_pmc_traffic.json "how"): quoted only when the profile is of this launch shape
     traffic = None
-    try:
-        prof = json.load(open(os.path.join(os.path.dirname(os.path.abspath(__file__)), "profiles", "r01_pmc_traffic.json")))
-        if prof["cells"] == ncell_local and eng.b == 3:
-            traffic = prof["kernels"]["tp::k_spmv_block<3, 7, 3, 0>"]["traffic_bytes"]
-    except (OSError, KeyError, ValueError):
-        pass
+    for prof_name in ("r02_pmc_traffic.json", "r01_pmc_traffic.json"):
+        try:
+            prof = json.load(open(os.path.join(ROOT, "profiles", prof_name)))
+            if prof["cells"] == ncell_local and eng.b == 3:
+                for kname, rec in prof["kernels"].items():
+                    if "k_ilu_solve" in kname:
+                        traffic = rec["traffic_bytes"]
+                if traffic is not None:
+                    break
+        except (OSError, KeyError, ValueError):
+            pass
+    desc = CONFIGS[args.config][0]
     out = {
-        "metric": "Newton steps/s, SPE10 60x220x85 two-phase (FGMRES its/s in config)",
+        "metric": "Newton steps/s, SPE10 60x220x85 two-phase (FGMRES its/s in config)" if args.config == "c4"
+                  else "Newton steps/s (FGMRES its/s in config), " + args.config,
         "value": nits/el,
         "unit": "Newton steps/s",
         "n_gpus": world,
@@ -163,21 +275,28 @@ def main():
         "dtype": "f64",
         "data": "synthetic",
         "config": {
-            "workload": "BASELINE config 4: two-phase 3D SPE10-like %dx%dx%d (synthetic default_rng(10) field), wells+heaters, "
-                        "pc_cptr, FGMRES rtol 1e-8, dt ramp from maxdt*2^-10 (maxdt 0.1 d)" % (model.geo.Nx, model.geo.Ny, model.geo.Nz),
+            "workload": "%s; grid %dx%dx%d (synthetic default_rng(10) field); FGMRES rtol %g; timed at dt = maxdt after an "
+                        "untimed spin-up along the reference's dt ramp" % (desc, model.geo.Nx, model.geo.Ny, model.geo.Nz,
+                                                                         eng.opts["ksp_rtol"]),
             "fgmres_its_per_s": lits/el,
             "newton_its": nits, "fgmres_its": lits, "failed_solves": model.failed_solves - f0,
-            "dt_days": [model.dt_vec[args.warmup]/86400.0, model.dt_vec[-1]/86400.0],
-            "slabs": "1-D along y" if world > 1 else "none",
-            "kernels_ms": dict(spmv_ms=ms, **extra),
+            "dt_days": [float(dts.min()), float(dts.max())],
+            "ms_per_fgmres_it": it_ms,
+            "ramp": ramp,
+            "slabs": "1-D along the slab axis" if world > 1 else "none",
+            "kernels_ms": km,
         },
-        "roofline": {"bound": "hbm", "achieved": achieved, "peak": HBM_PEAK_GBS, "unit": "GB/s",
-                     "frac": achieved/HBM_PEAK_GBS, "traffic": traffic,
-                     "kernel": "k_spmv_block<3,7,3,0>", "bytes_per_cell": bpc, "cells_per_launch": ncell_local,
-                     "avg_ms": ms, "other_kernels": others},
+        "roofline": {"bound": "hbm", "achieved": ilu["achieved_GBs"], "peak": HBM_PEAK_GBS, "unit": "GB/s",
+                     "frac": ilu["frac"], "traffic": traffic,
+                     "kernel": "k_ilu_solve<%d>" % eng.b, "bytes_per_cell": ilu["bytes_per_cell"],
+                     "cells_per_launch": ncell_local, "avg_ms": ilu["avg_ms"], "other_kernels": others},
     }
-    if not args.no_cpu_baseline and world == 1:
-        out["cpu_baseline"] = cpu_baseline()
+    if want_cpu:
+        try:
+            out["cpu_baseline"] = cpu_baseline(args.config, Nxyz, u_start, uold_start, dt_start, args.cpu_budget)
+        except Exception as e:          # the CPU leg must never take the GPU measurement down with it
+            out["cpu_baseline"] = {"value": None, "unit": "Newton steps/s", "cores": 0, "kind": "port",
+                                   "sample": "cpu leg failed: %r" % (e,)}
     print(json.dumps(out))
 
 

@@ -19,5 +19,12 @@ print("its", tot, flush=True)
 print("steps %.3fs" % (time.time() - t), "failed", m.failed_solves)
 e = m.engine
 e.lib.tp_jacobian(e.ctx); e.pc_setup()
+if os.environ.get("TP_DEBUG"):      # address map of the native libraries (to decode a crash stack)
+    for ln in open("/proc/self/maps"):
+        if " r-xp " in ln and any(k in ln for k in ("amdhip", "hsa-runtime", "rocprof", "thermalporous", "libc.so", "rocr", "roctx")):
+            print("[maps]", ln.strip(), flush=True)
+SYNC_EACH = os.environ.get("KT_ONLY")
 for w, nm in enumerate(["spmv", "ilu_solve", "amg_vcycle", "assembly", "pc_apply", "pc_setup", "ilu_factor"]):
+    if SYNC_EACH and nm not in SYNC_EACH.split(","):
+        continue
     print("%-12s %.3f ms" % (nm, e.time_kernel(w, 20)), flush=True)

@@ -1,0 +1,125 @@
+"""oracle/cport (the C++/OpenMP restatement: bench.py's measured CPU baseline and the checker for full-size cases)
+against the numpy oracle it mirrors function for function: every stage to round-off, identical iteration counts.
+Both are test infrastructure; parity with the reference itself is unpinned (oracle/__init__.py)."""
+import numpy as np
+import pytest
+
+import cases
+import oracle.linalg as la
+from oracle.engine import OracleEngine
+from oracle.cport import CPortEngine
+
+
+def rel2(a, b):
+    return np.linalg.norm((a - b).ravel())/max(np.linalg.norm(b.ravel()), 1e-300)
+
+
+CASES = [
+    ("c1_1ph_2d", cases.c1_homogeneous, dict(N=12, nphase=1), dict(pc="cpr")),
+    ("c3_2ph_2d", cases.c3_spe10_2d, dict(Nx=14, Ny=19, nphase=2), dict(pc="cptr")),
+    ("c2_1ph_2d_qi", cases.c3_spe10_2d, dict(Nx=14, Ny=19, nphase=1), dict(pc="cpr", decoup="QI")),
+    ("c4_2ph_3d", cases.c4_spe10_3d, dict(Nx=7, Ny=13, Nz=9, nphase=2), dict(pc="cptr")),
+    ("c4_1ph_3d_ti", cases.c4_spe10_3d, dict(Nx=7, Ny=13, Nz=9, nphase=1), dict(pc="cpr", decoup="TI")),
+    ("c4_2ph_3d_tiles", cases.c4_spe10_3d, dict(Nx=11, Ny=13, Nz=17, nphase=2), dict(pc="cptr", ilu_tile=(5, 4, 7))),
+    ("c4_2ph_3d_midskip", cases.c4_spe10_3d, dict(Nx=16, Ny=18, Nz=16, nphase=2), dict(pc="cptr", amg_full_levels=1)),
+    ("c4_2ph_3d_fp32amg", cases.c4_spe10_3d, dict(Nx=9, Ny=14, Nz=8, nphase=2), dict(pc="cptr", amg_single=True)),
+    ("c4_2ph_3d_qitemp", cases.c4_spe10_3d, dict(Nx=9, Ny=10, Nz=5, nphase=2), dict(pc="cpr", decoup="QI_temp")),
+    ("c4_2ph_3d_titemp", cases.c4_spe10_3d, dict(Nx=7, Ny=8, Nz=6, nphase=2), dict(pc="cpr", decoup="TI_temp")),
+    ("c4_2ph_3d_qi_a11", cases.c4_spe10_3d, dict(Nx=7, Ny=8, Nz=6, nphase=2), dict(pc="cptr", decoup="QI", schur_a11=True)),
+    ("c4_1ph_3d_fscd", cases.c4_spe10_3d, dict(Nx=7, Ny=13, Nz=9, nphase=1), dict(pc="fieldsplit_cd")),
+    ("c4_2ph_3d_3slabs", cases.c4_spe10_3d, dict(Nx=9, Ny=14, Nz=8, nphase=2), dict(pc="cptr", nslabs=3)),
+    ("c4_2ph_3d_oneblock", cases.c4_spe10_3d, dict(Nx=9, Ny=14, Nz=8, nphase=2), dict(pc="cptr", ilu_tile=(1 << 30,)*3)),
+]
+
+
+@pytest.mark.parametrize("name,builder,kw,opts", CASES, ids=[c[0] for c in CASES])
+def test_cport_matches_numpy_oracle(name, builder, kw, opts):
+    spec, u0, *_ = builder(**kw)
+    o, c = OracleEngine(spec, opts), CPortEngine(spec, opts)
+    u = cases.perturbed_state(spec, seed=3)
+    for e in (o, c):
+        e.set_state(u0)
+        e.set_old(u0)
+        e.set_dt(8640.0)
+        e.set_state(u)
+    schur = opts["pc"] in ("cptr", "fieldsplit_cd")
+    Ro, Rc = o.residual(), c.residual()
+    for f in range(o.b):
+        assert np.abs(Rc[f] - Ro[f]).max() <= 1e-13*np.abs(Ro[f]).max()
+    out_o, out_c = o.jacobian(want_schur=schur), c.jacobian(want_schur=schur)
+    Jo, Jc = (out_o[0], out_c[0]) if schur else (out_o, out_c)
+    for r in range(o.b):
+        for q in range(o.b):
+            scale = np.abs(Jo[:, r, q]).max()
+            assert np.abs(Jc[:, r, q] - Jo[:, r, q]).max() <= 1e-13*scale + 0.0
+    if schur:
+        assert np.abs(out_c[1] - out_o[1]).max() <= 1e-13*np.abs(out_o[1]).max()
+    # linear stages on a milder state
+    u = cases.perturbed_state(spec, seed=5, amp=0.3)
+    for e in (o, c):
+        e.set_state(u)
+    out = o.jacobian(want_schur=schur)
+    J, Sm = out if schur else (out, None)
+    c.jacobian(want_schur=schur)
+    o.pc.setup(J, Sm)
+    c.pc_setup()
+    x = np.random.default_rng(11).standard_normal(J.shape[1:2] + J.shape[3:])
+    tol = 1e-6 if opts.get("amg_single") else 1e-11      # fp32 storage: a few entries round differently
+    assert rel2(c.spmv(x), la.spmv_block(J, x)) < 1e-14
+    assert rel2(c.ilu_solve(x), o.pc.ilu.solve(x)) < 1e-13
+    assert rel2(c.vcycle(0, x[0]), o.pc.amg_p.vcycle(x[0])) < tol
+    assert rel2(c.stage1(x), o.pc.stage1(x)) < tol
+    assert rel2(c.pc_apply(x), o.pc.apply(x)) < tol
+    F = o.residual()
+    d_o, its_o, reason_o, _ = la.fgmres(lambda v: la.spmv_block(J, v), o.pc.apply, F, rtol=o.opts["ksp_rtol"],
+                                        maxit=o.opts["ksp_max_it"], restart=o.opts["ksp_restart"])
+    d_c, its_c, reason_c, _ = c.fgmres(F)
+    assert reason_c == reason_o == 2 and its_c == its_o
+    assert rel2(d_c, d_o) < 1e-7
+
+
+NEWTON = [
+    ("c1", cases.c1_homogeneous, dict(N=12, nphase=1), dict(pc="cpr"), 86400.0),
+    ("c3", cases.c3_spe10_2d, dict(Nx=14, Ny=19, nphase=2), dict(pc="cptr", ksp_rtol=1e-8, snes_max_it=25), 864.0),
+    ("c4", cases.c4_spe10_3d, dict(Nx=7, Ny=13, Nz=9, nphase=2), dict(pc="cptr", ksp_rtol=1e-8, snes_max_it=25), 86.4),
+]
+
+
+@pytest.mark.parametrize("name,builder,kw,opts,dt", NEWTON, ids=[c[0] for c in NEWTON])
+def test_cport_newton_matches_numpy_oracle(name, builder, kw, opts, dt):
+    spec, u0, *_ = builder(**kw)
+    o, c = OracleEngine(spec, opts), CPortEngine(spec, opts)
+    for e in (o, c):
+        e.set_state(u0)
+    for step in range(2):
+        for e in (o, c):
+            e.set_old()
+            e.set_dt(dt)
+        ro, rc = o.newton_solve(), c.newton_solve()
+        assert ro["reason"] > 0 and rc["reason"] == ro["reason"]
+        assert (rc["nits"], rc["lits"]) == (ro["nits"], ro["lits"])
+        uo, uc = o.get_state(), c.get_state()
+        for f in range(o.b):
+            assert rel2(uc[f], uo[f]) < 1e-11
+
+
+def test_cport_time_loop_and_budget():
+    """The host time loop drives the port like any engine; a time budget stops a solve BETWEEN Newton iterations."""
+    from thermalporous_amd.twophase import TwoPhase
+    res = []
+    for factory in (OracleEngine, CPortEngine):
+        spec, u0, p, g, cse = cases.c3_spe10_2d(16, 22, 2)
+        m = TwoPhase(g, cse, p, end=0.004, maxdt=0.002, solver_parameters="pc_cptr", filename=None, verbosity=False,
+                     _engine_factory=factory)
+        m.solve()
+        res.append((m.nits_vec, m.lits_vec, m.dt_vec, [m.u.dat.data_ro[f].copy() for f in range(3)]))
+    assert res[0][:2] == res[1][:2] and np.allclose(res[0][2], res[1][2])
+    for f in range(3):
+        assert rel2(res[1][3][f], res[0][3][f]) < 1e-10
+    spec, u0, *_ = cases.c4_spe10_3d(Nx=7, Ny=13, Nz=9, nphase=2)
+    c = CPortEngine(spec, dict(pc="cptr", ksp_rtol=1e-8, snes_max_it=25))
+    c.set_state(u0)
+    c.set_old()
+    c.set_dt(86.4)
+    r = c.newton_solve(budget_s=1e-9)         # at least one Newton iteration always completes
+    assert r["nits"] == 1 and r["complete"] == 0 and r["reason"] == 0 and r["lits"] > 0

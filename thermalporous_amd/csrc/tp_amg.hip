@@ -687,6 +687,7 @@ static LevelDevT<R> dev_of(const AmgLevel *L, int level, const tp_options &o) {
 void amg_build(tp_ctx *c, Amg *&amg, const GridDev &g0, const double strength[3]) {
     delete amg;
     amg = new Amg();
+    c->graph_epoch++;            // a new hierarchy may reuse the old one's addresses: never replay graphs across a rebuild
     amg->single = c->opt.amg_single != 0;
     const int n[3] = {g0.n0, g0.n1, g0.n2};
     amg->sched = schedule(n, strength, std::max(1, c->opt.amg_min_cells));

@@ -314,6 +314,7 @@ int tp_set_options(tp_ctx *c, const tp_options *opt) {
     if (amg_changed) { delete c->amg_p; c->amg_p = nullptr; delete c->amg_T; c->amg_T = nullptr; }
     if (schur_of(*opt) && c->Sm.n == 0) c->Sm.alloc((size_t)7 * c->g.ntot);
     c->pc_ready = false;
+    c->graph_epoch++;            // any option may change the captured kernel sequence: drop the pc_apply graphs
     TP_API_END
 }
 
@@ -397,6 +398,8 @@ int tp_finalize_fields(tp_ctx *c) {
     c->fields_ready = true;
     delete c->amg_p; c->amg_p = nullptr;
     delete c->amg_T; c->amg_T = nullptr;
+    c->pc_ready = false;
+    c->graph_epoch++;
     TP_API_END
 }
 
@@ -673,9 +676,7 @@ int tp_newton_solve(tp_ctx *c, tp_solve_info *info) {
 int tp_time_kernel(tp_ctx *c, int32_t which, int32_t reps, double *ms_avg) {
     TP_API_BEGIN
     TP_REQUIRE(reps > 0 && ms_avg, "bad arguments");
-    const size_t nv = (size_t)c->b * c->g.ntot;
-    if (c->w1.n < nv) { c->w1.alloc(nv); c->w2.alloc(nv); c->w3.alloc(nv); c->w4.alloc(nv); }
-    if (c->dx.n < nv) c->dx.alloc(nv);
+    ensure_work(c);          // (w3 needs three planes even when b == 2: tp_solver.hip)
     if (which != 3) TP_REQUIRE(c->jac_ready, "Jacobian not assembled");
     if (which == 1 || which == 2 || which == 4) TP_REQUIRE(c->pc_ready, "preconditioner not set up");
     auto run = [&]() {

@@ -259,6 +259,7 @@ void slab_of(const tp_ctx *c, int rank, int &lo, int &hi);
 // gather `nplanes` slab-distributed cell planes into arrays on the global grid (every rank gets all slabs)
 void gather_slabs(tp_ctx *c, const double *local, long lstride, double *global, long gstride, int nplanes);
 // solver
+void ensure_work(tp_ctx *c);          // scratch vectors w1..w4, dx of the preconditioner / Krylov loops
 void pc_setup(tp_ctx *c);
 void stage1_apply(tp_ctx *c, const double *x, double *y, bool zero_secondary = true);
 void pc_apply(tp_ctx *c, const double *x, double *y);

@@ -472,6 +472,7 @@ void ilu_setup(tp_ctx *c) {
     d.ntiles = d.nt0 * d.nt1 * d.nt2;
     d.nsteps = t0 + t1 + t2 - 2;
     d.slots = (long)d.ntiles * d.nsteps * 64;
+    c->graph_epoch++;            // new tile layout / factor buffers: captured pc_apply graphs are stale
     if (c->b == 3) alloc_factor<3>(d); else alloc_factor<2>(d);
 }
 

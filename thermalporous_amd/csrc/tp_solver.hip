@@ -17,10 +17,18 @@
 namespace tp {
 
 // ------------------------------------------------------------------------------------------------
-static void ensure_work(tp_ctx *c) {
+void ensure_work(tp_ctx *c) {
     const size_t nv = (size_t)c->b * c->g.ntot;
-    // w3 holds the Schur stage's r0, r1 and t: three planes even for the 2-field single-phase system
-    if (c->w1.n < nv) { c->w1.alloc(nv); c->w2.alloc(nv); c->w3.alloc(std::max(nv, (size_t)3 * c->g.ntot)); c->w4.alloc(nv); }
+    // w3 holds the Schur stage's r0, r1 and t: three planes even for the 2-field single-phase system.
+    // Every buffer is tested on its own size: nothing may assume that whoever allocated w1 also sized w3.
+    const size_t n3 = std::max(nv, (size_t)3 * c->g.ntot);
+    bool grew = false;
+    if (c->w1.n < nv) { c->w1.alloc(nv); grew = true; }
+    if (c->w2.n < nv) { c->w2.alloc(nv); grew = true; }
+    if (c->w3.n < n3) { c->w3.alloc(n3); grew = true; }
+    if (c->w4.n < nv) { c->w4.alloc(nv); grew = true; }
+    if (c->dx.n < nv) { c->dx.alloc(nv); grew = true; }
+    if (grew) c->graph_epoch++;          // captured pc_apply graphs hold the old addresses
 }
 
 // mean interior-face transmissibility per axis over the GLOBAL grid (sum/count all-reduced over slabs)
@@ -232,6 +240,7 @@ void pc_apply(tp_ctx *c, const double *x, double *y) {
     TP_REQUIRE(c->pc_ready, "pc_apply before pc_setup");
     static const bool use_graph = !(getenv("TP_GRAPH") && atoi(getenv("TP_GRAPH")) == 0);
     c->vcycles += schur_of(c->opt) ? 3 : 1;
+    ensure_work(c);                      // never allocate inside a stream capture
     if (!use_graph || c->dist) {
         pc_apply_body(c, x, y);
         return;
@@ -241,11 +250,15 @@ void pc_apply(tp_ctx *c, const double *x, double *y) {
         c->pc_graphs.clear();
         c->pc_graph_epoch = c->graph_epoch;
     }
+    // TP_DEBUG=2: one line per HIP graph call (used to locate the profiler crash described in DESIGN.md 6)
+    static const bool trace = getenv("TP_DEBUG") && atoi(getenv("TP_DEBUG")) >= 2;
+    auto say = [&](const char *what) { if (trace) { fprintf(stderr, "[tp] pc_apply(%p,%p): %s\n", (const void *)x, (void *)y, what); fflush(stderr); } };
     hipGraphExec_t exec = nullptr;
     for (auto &gph : c->pc_graphs)
         if (gph.x == x && gph.y == y) { exec = gph.exec; break; }
     if (!exec) {
         hipGraph_t graph = nullptr;
+        say("begin capture");
         TP_HIP(hipStreamBeginCapture(c->stream, hipStreamCaptureModeThreadLocal));
         try {
             pc_apply_body(c, x, y);
@@ -254,12 +267,16 @@ void pc_apply(tp_ctx *c, const double *x, double *y) {
             if (graph) (void)hipGraphDestroy(graph);
             throw;
         }
+        say("end capture");
         TP_HIP(hipStreamEndCapture(c->stream, &graph));
+        say("instantiate");
         TP_HIP(hipGraphInstantiate(&exec, graph, nullptr, nullptr, 0));
         TP_HIP(hipGraphDestroy(graph));
         c->pc_graphs.push_back({x, y, exec});
     }
+    say("launch");
     TP_HIP(hipGraphLaunch(exec, c->stream));
+    say("launched");
 }
 
 // ------------------------------------------------------------------------------------------------

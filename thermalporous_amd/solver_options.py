@@ -2,7 +2,8 @@
 
 The reference configures its whole linear/nonlinear stack through PETSc option dicts
 (singlephase.py:289-354,410-439; twophase.py:416-433,531-597,929-997).  The hot path honours the
-subset that selects the solvers it implements and rejects everything else loudly:
+subset that selects the solvers it implements and rejects everything else loudly -- every key is either
+CONSUMED (and its value checked against what is implemented), purely cosmetic (monitors/views), or an error:
 
   snes_type newtonls  (line search `basic`: Firedrake's default, not settable in the reference)
   ksp_type fgmres|gmres (right preconditioning), ksp_rtol/atol/max_it, ksp_gmres_restart
@@ -18,8 +19,49 @@ ilu_tile.  Two-phase string presets are layered on plain Newton-Krylov, not on t
 experimental FAS nonlinear preconditioner (twophase.py:927; needs mesh hierarchies + MUMPS).
 """
 
+# keys that only print / name the matrix type: no effect on the arithmetic
 _IGNORED = {"snes_monitor", "snes_converged_reason", "ksp_converged_reason", "ksp_view", "snes_view", "ksp_monitor",
-            "mat_type", "ksp_pc_side", "snes_linesearch_type", "ksp_monitor_residuals"}
+            "ksp_monitor_residuals"}
+
+# every PETSc key the hot path CONSUMES (checked against the value it implements) -- anything else raises
+_VCYCLE_SUFFIXES = {"ksp_type": "preonly", "pc_type": "hypre", "pc_hypre_type": "boomeramg",
+                    "pc_hypre_boomeramg_max_iter": 1}
+
+
+def _take_vcycle(sp, prefix, used):
+    """``<prefix>`` must configure exactly the reference's one-V-cycle solver (v_cycle dicts, singlephase.py:303-307,
+    twophase.py:478-482); hypre tuning keys are not honoured and therefore rejected."""
+    for suf, want in _VCYCLE_SUFFIXES.items():
+        k = prefix + suf
+        if k not in sp:
+            if suf == "pc_hypre_boomeramg_max_iter":      # PETSc's default is already 1
+                continue
+            raise NotImplementedError("%s missing: the stage-1 solver must be one BoomerAMG V-cycle (v_cycle)" % k)
+        if sp[k] != want:
+            raise NotImplementedError("%s = %r: only %r (one V-cycle per application)" % (k, sp[k], want))
+        used.add(k)
+    for k in sp:
+        if k.startswith(prefix + "pc_hypre_") and k not in used:
+            raise NotImplementedError("%s: hypre tuning options do not apply to this build's own AMG" % k)
+
+
+def _take(sp, used, key, allowed=None, default=None):
+    """Consume `key`; `allowed` = the values the hot path implements."""
+    if key not in sp:
+        return default
+    v = sp[key]
+    if allowed is not None and v not in allowed:
+        raise NotImplementedError("%s = %r is not implemented on the hot path (supported: %s)"
+                                  % (key, v, ", ".join(repr(a) for a in allowed)))
+    used.add(key)
+    return v
+
+
+def _reject_unused(sp, used):
+    for k in sp:
+        if k in used or k in _IGNORED:
+            continue
+        raise KeyError("solver parameter %r is not consumed by the hot path (it would be silently ignored)" % k)
 
 _V_CYCLE = {"ksp_type": "preonly", "pc_type": "hypre", "pc_hypre_type": "boomeramg",
             "pc_hypre_boomeramg_max_iter": 1}
@@ -42,90 +84,143 @@ def engine_options(solver_parameters, model_name, decoup="No"):
     o = dict(DEFAULT_OPTS)
     o["decoup"] = decoup
     o["schur_a11"] = False
+    used = set()
     build_keys = ("amg_omega", "amg_nu", "amg_min_cells", "amg_full_levels", "amg_coarse_pre", "amg_coarse_post", "amg_mid_skip", "amg_tail_post", "amg_single",
                   "amg_gather_cells", "ilu_tile")
     for k in build_keys:
         if k in sp:
             o[k] = sp.pop(k)
-    if sp.get("snes_type", "newtonls") != "newtonls":
-        raise NotImplementedError("snes_type %r: only newtonls is on the hot path" % sp["snes_type"])
-    if sp.get("ksp_type", "gmres") not in ("fgmres", "gmres"):
-        raise NotImplementedError("ksp_type %r: only (f)gmres with right preconditioning" % sp["ksp_type"])
-    if sp.get("ksp_type", "gmres") == "gmres" and sp.get("ksp_pc_side", "right") != "right":
-        raise NotImplementedError("left-preconditioned GMRES is not implemented")
+    # ---- Newton / Krylov (singlephase.py:289-301, twophase.py:416-433) --------------------------------------
+    _take(sp, used, "snes_type", ("newtonls",))
+    # Firedrake's default line search is `basic`; the reference never sets another one on its Newton-Krylov path
+    # (l2 only inside the FAS presets, twophase.py:437): anything but basic would silently change the algorithm
+    _take(sp, used, "snes_linesearch_type", ("basic",))
+    _take(sp, used, "mat_type", ("aij",))
+    ksp = _take(sp, used, "ksp_type", ("fgmres", "gmres"), "gmres")
+    side = _take(sp, used, "ksp_pc_side", ("right",))
+    if ksp == "gmres" and side is None:
+        raise NotImplementedError("ksp_type gmres without ksp_pc_side: PETSc would precondition from the LEFT; only "
+                                  "right-preconditioned (F)GMRES is implemented (the reference sets ksp_pc_side right, "
+                                  "singlephase.py:296)")
     for k_src, k_dst in (("ksp_rtol", "ksp_rtol"), ("ksp_atol", "ksp_atol"), ("ksp_max_it", "ksp_max_it"),
                          ("ksp_gmres_restart", "ksp_restart"), ("snes_max_it", "snes_max_it"),
                          ("snes_rtol", "snes_rtol"), ("snes_atol", "snes_atol"), ("snes_stol", "snes_stol")):
         if k_src in sp:
             o[k_dst] = sp[k_src]
-    if sp.get("pc_type") == "fieldsplit":
-        # pc_fieldsplit_cd (singlephase.py:309-319): Schur FULL on (p,T), V-cycle on A_pp, ConvDiffSchurPC on S
-        a11 = sp.get("pc_fieldsplit_schur_precondition") == "a11" and sp.get("fieldsplit_1_pc_type") == "hypre"
-        if sp.get("pc_fieldsplit_type") != "schur" or str(sp.get("pc_fieldsplit_schur_fact_type", "")).upper() != "FULL" \
-                or not (a11 or (str(sp.get("fieldsplit_1_pc_python_type", "")).endswith("ConvDiffSchurPC")
-                                and "pc_fieldsplit_schur_precondition" not in sp)):
+            used.add(k_src)
+    pc_type = _take(sp, used, "pc_type", ("fieldsplit", "composite"))
+    if pc_type is None:
+        raise NotImplementedError("pc_type missing: only the composite CPR/CPTR preconditioners and pc_fieldsplit_cd/_a11 "
+                                  "are on the hot path")
+    if pc_type == "fieldsplit":
+        # pc_fieldsplit_cd (singlephase.py:309-319): Schur FULL on (p,T), V-cycle on A_pp, ConvDiffSchurPC on S;
+        # pc_fieldsplit_a11 (:331-338): A_TT stands in for the Schur complement
+        _take(sp, used, "pc_fieldsplit_type", ("schur",))
+        fact = str(_take(sp, used, "pc_fieldsplit_schur_fact_type", None, "")).upper()
+        pre = _take(sp, used, "pc_fieldsplit_schur_precondition", ("a11",))
+        if "pc_fieldsplit_type" not in used or fact != "FULL":
             raise NotImplementedError("fieldsplit preconditioners on the hot path: pc_fieldsplit_cd (schur FULL with "
                                       "ConvDiffSchurPC) and pc_fieldsplit_a11; selfp / additive variants are not")
-        o["schur_a11"] = bool(a11)
+        _take_vcycle(sp, "fieldsplit_0_", used)
+        if pre == "a11":
+            _take_vcycle(sp, "fieldsplit_1_", used)
+        else:
+            _take(sp, used, "fieldsplit_1_ksp_type", ("preonly",))
+            _take(sp, used, "fieldsplit_1_pc_type", ("python",))
+            if not str(_take(sp, used, "fieldsplit_1_pc_python_type", None, "")).endswith("ConvDiffSchurPC"):
+                raise NotImplementedError("fieldsplit_1 must be ConvDiffSchurPC (pc_fieldsplit_cd) or a V-cycle on A_11 "
+                                          "(pc_fieldsplit_a11); selfp is not on the hot path")
+            _take_vcycle(sp, "fieldsplit_1_schur_", used)
+        o["schur_a11"] = pre == "a11"
         if model_name == "Two-phase":
             raise NotImplementedError("pc_fieldsplit_cd is the single-phase block preconditioner")
         if o["decoup"] != "No":
             raise NotImplementedError("pc_fieldsplit_cd has no decoupling stage")
         o["pc"] = "fieldsplit_cd"
-        for k in sp:
-            if not (k in _IGNORED or k.startswith(("fieldsplit_", "pc_", "ksp_", "snes_"))):
-                raise KeyError("unknown solver parameter %r" % k)
+        _reject_unused(sp, used)
         return o
-    if sp.get("pc_type") == "composite" and sp.get("pc_composite_pcs") == "fieldsplit,bjacobi":
+    # ---- composite multiplicative (stage 1, bjacobi/ILU(0)) -----------------------------------------------------
+    _take(sp, used, "pc_composite_type", ("multiplicative",))
+    pcs = _take(sp, used, "pc_composite_pcs", ("python,bjacobi", "fieldsplit,bjacobi"))
+    if pcs is None:
+        raise NotImplementedError("pc_composite_pcs missing")
+    # stage 2: bjacobi + ILU(0) (singlephase.py:348-349); block count: see engine.tiles_for_blocks
+    _take(sp, used, "sub_1_sub_pc_type", ("ilu",))
+    if int(_take(sp, used, "sub_1_sub_pc_factor_levels", None, 0)) != 0:
+        raise NotImplementedError("stage 2 must be ILU(0) (pc_cprilu1_gmres is not on the hot path)")
+    nb = _take(sp, used, "sub_1_pc_bjacobi_blocks")
+    if nb is not None:
+        o["bjacobi_blocks"] = int(nb)
+    _take(sp, used, "sub_0_cpr_decoup", ("No", "QI", "TI", "QI_temp", "TI_temp"))    # read by the model class (:441-444)
+    if pcs == "fieldsplit,bjacobi":
         # the reference's pure-PETSc emulations of its python stage-1 classes (singlephase.py:355-368,
         # twophase.py:619-634,670-699): additive fieldsplit whose second split is "gmres, max_it 0, pc none" -- i.e.
         # returns zero, exactly the y_nonp = 0 of CPRStage1PC/CPTRStage1PC.apply -- with decoupling "No".
         # pc_cpr_gmres == pc_cpr and pc_cptr_gmres == pc_cptr (the two-phase default, twophase.py:930) as algebra.
-        if sp.get("pc_composite_type", "multiplicative") != "multiplicative" or sp.get("sub_0_pc_fieldsplit_type") != "additive" \
-                or sp.get("sub_0_fieldsplit_1_ksp_type") != "gmres" or int(sp.get("sub_0_fieldsplit_1_ksp_max_it", -1)) != 0 \
-                or sp.get("sub_0_fieldsplit_1_pc_type") != "none":
+        _take(sp, used, "sub_0_pc_fieldsplit_type", ("additive",))
+        _take(sp, used, "sub_0_fieldsplit_1_ksp_type", ("gmres",))
+        _take(sp, used, "sub_0_fieldsplit_1_pc_type", ("none",))
+        if "sub_0_pc_fieldsplit_type" not in used or "sub_0_fieldsplit_1_ksp_type" not in used \
+                or int(_take(sp, used, "sub_0_fieldsplit_1_ksp_max_it", None, -1)) != 0 \
+                or "sub_0_fieldsplit_1_pc_type" not in used:
             raise NotImplementedError("fieldsplit,bjacobi composite: only the *_gmres emulations of pc_cpr / pc_cptr")
-        if sp.get("sub_1_sub_pc_type", "ilu") != "ilu" or int(sp.get("sub_1_sub_pc_factor_levels", 0)) != 0:
-            raise NotImplementedError("stage 2 must be ILU(0) (pc_cprilu1_gmres is not on the hot path)")
         if o["decoup"] != "No":
             raise NotImplementedError("the fieldsplit emulations have no decoupling stage")
-        if sp.get("sub_0_fieldsplit_0_pc_type") == "hypre":
-            if sp.get("sub_0_pc_fieldsplit_0_fields", "0") != "0":
+        f0 = _take(sp, used, "sub_0_pc_fieldsplit_0_fields", None, "0")
+        f1 = _take(sp, used, "sub_0_pc_fieldsplit_1_fields")
+        first = _take(sp, used, "sub_0_fieldsplit_0_pc_type", ("hypre", "fieldsplit"))
+        if first == "hypre":
+            if f0 != "0":
                 raise NotImplementedError("system AMG on several fields (pc_cptramg_gmres) is not on the hot path")
+            _take_vcycle(sp, "sub_0_fieldsplit_0_", used)
             o["pc"] = "cpr"
-        elif sp.get("sub_0_fieldsplit_0_pc_type") == "fieldsplit" \
-                and sp.get("sub_0_fieldsplit_0_pc_fieldsplit_type") == "schur" \
-                and str(sp.get("sub_0_fieldsplit_0_pc_fieldsplit_schur_fact_type", "")).upper() == "FULL" \
-                and str(sp.get("sub_0_fieldsplit_0_fieldsplit_1_pc_python_type", "")).endswith("ConvDiffSchurTwoPhasesPC"):
+        elif first == "fieldsplit":
+            _take(sp, used, "sub_0_fieldsplit_0_pc_fieldsplit_type", ("schur",))
+            fact = str(_take(sp, used, "sub_0_fieldsplit_0_pc_fieldsplit_schur_fact_type", None, "")).upper()
+            _take(sp, used, "sub_0_fieldsplit_0_fieldsplit_1_ksp_type", ("preonly",))
+            _take(sp, used, "sub_0_fieldsplit_0_fieldsplit_1_pc_type", ("python",))
+            py = str(_take(sp, used, "sub_0_fieldsplit_0_fieldsplit_1_pc_python_type", None, ""))
+            if "sub_0_fieldsplit_0_pc_fieldsplit_type" not in used or fact != "FULL" or not py.endswith("ConvDiffSchurTwoPhasesPC"):
+                raise NotImplementedError("unsupported first split of the fieldsplit,bjacobi composite")
+            if f0 not in ("0,1", "0, 1") or f1 not in (None, "2"):
+                raise NotImplementedError("pc_cptr_gmres splits fields (0,1 | 2)")
+            _take_vcycle(sp, "sub_0_fieldsplit_0_fieldsplit_0_", used)
+            _take_vcycle(sp, "sub_0_fieldsplit_0_fieldsplit_1_schur_", used)
             if model_name != "Two-phase":
                 raise NotImplementedError("pc_cptr_gmres needs the two-phase model")
             o["pc"] = "cptr"
         else:
             raise NotImplementedError("unsupported first split of the fieldsplit,bjacobi composite "
                                       "(mg/LU/system-AMG variants are not on the hot path)")
-        for k in sp:
-            if not (k in _IGNORED or k.startswith(("sub_0_", "sub_1_", "pc_", "ksp_", "snes_"))):
-                raise KeyError("unknown solver parameter %r" % k)
+        _reject_unused(sp, used)
         return o
-    if sp.get("pc_type") != "composite" or sp.get("pc_composite_type", "multiplicative") != "multiplicative" \
-            or sp.get("pc_composite_pcs") != "python,bjacobi":
-        raise NotImplementedError(
-            "only the composite multiplicative 'python,bjacobi' preconditioners (pc_cpr*, pc_cptr) are on the hot "
-            "path; got pc_type=%r pc_composite_pcs=%r" % (sp.get("pc_type"), sp.get("pc_composite_pcs")))
-    pytype = str(sp.get("sub_0_pc_python_type", ""))
+    pytype = str(_take(sp, used, "sub_0_pc_python_type", None, ""))
     if pytype.endswith("CPRStage1PC"):
         o["pc"] = "cpr"
+        _take_vcycle(sp, "sub_0_cpr_stage1_", used)
     elif pytype.endswith("CPTRStage1PC"):
         if model_name != "Two-phase":
             raise NotImplementedError("CPTRStage1PC needs the two-phase model")
         o["pc"] = "cptr"
-        if sp.get("sub_0_cpr_stage1_pc_type") != "fieldsplit":
+        if _take(sp, used, "sub_0_cpr_stage1_pc_type", ("fieldsplit",)) is None:
             raise NotImplementedError("CPTRStage1PC is implemented with the fieldsplit-Schur stage-1 solver of "
                                       "pc_cptr; system-AMG/LU variants (pc_cptramg*, pc_cptrlu*) are not")
-        pre = sp.get("sub_0_cpr_stage1_pc_fieldsplit_schur_precondition")
-        if pre not in (None, "a11"):
-            raise NotImplementedError("Schur preconditioning %r (only the ConvDiffSchurTwoPhasesPC operator and a11)" % pre)
+        _take(sp, used, "sub_0_cpr_stage1_pc_fieldsplit_type", ("schur",))
+        fact = str(_take(sp, used, "sub_0_cpr_stage1_pc_fieldsplit_schur_fact_type", None, "")).upper()
+        if "sub_0_cpr_stage1_pc_fieldsplit_type" not in used or fact != "FULL":
+            raise NotImplementedError("CPTR stage 1: fieldsplit schur FULL only (twophase.py:536-538)")
+        pre = _take(sp, used, "sub_0_cpr_stage1_pc_fieldsplit_schur_precondition", ("a11",))
         o["schur_a11"] = pre == "a11"                   # pc_cptr_a11 (twophase.py:598-616)
+        _take_vcycle(sp, "sub_0_cpr_stage1_fieldsplit_0_", used)
+        if pre == "a11":
+            _take_vcycle(sp, "sub_0_cpr_stage1_fieldsplit_1_", used)
+        else:
+            _take(sp, used, "sub_0_cpr_stage1_fieldsplit_1_ksp_type", ("preonly",))
+            _take(sp, used, "sub_0_cpr_stage1_fieldsplit_1_pc_type", ("python",))
+            py = str(_take(sp, used, "sub_0_cpr_stage1_fieldsplit_1_pc_python_type", None, ""))
+            if not py.endswith("ConvDiffSchurTwoPhasesPC"):
+                raise NotImplementedError("CPTR stage 1: the Schur split must be ConvDiffSchurTwoPhasesPC or a11")
+            _take_vcycle(sp, "sub_0_cpr_stage1_fieldsplit_1_schur_", used)
     else:
         raise NotImplementedError("sub_0_pc_python_type %r" % pytype)
     if o["decoup"] not in ("No", "QI", "TI", "QI_temp", "TI_temp"):
@@ -133,11 +228,5 @@ def engine_options(solver_parameters, model_name, decoup="No"):
     if o["decoup"].endswith("_temp") and (o["pc"] != "cpr" or model_name != "Two-phase"):
         raise NotImplementedError("QI_temp/TI_temp decouple temperature AND saturation from the pressure: "
                                   "two-phase pc_cpr only (preconditioners.py:367-368)")
-    if sp.get("sub_1_sub_pc_type", "ilu") != "ilu" or int(sp.get("sub_1_sub_pc_factor_levels", 0)) != 0:
-        raise NotImplementedError("stage 2 must be ILU(0)")
-    known_prefixes = ("sub_0_", "sub_1_", "pc_", "ksp_", "snes_")
-    for k in sp:
-        if k in _IGNORED or k.startswith(known_prefixes):
-            continue
-        raise KeyError("unknown solver parameter %r" % k)
+    _reject_unused(sp, used)
     return o

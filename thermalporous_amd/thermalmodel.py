@@ -236,7 +236,12 @@ class ThermalModel:
                     try:
                         self.solver.solve()
                     except exceptions.ConvergenceError:
+                        # the reference halves dt here AND again at the top of the loop (:211-217): dt/4 per failed re-solve
                         self.failed_solves += 1
+                        self.dt.assign(self.dt.values()[0]*0.5)
+                        u.assign(u_)
+                        if self.dt.values()[0] < 1e-12*DAY:
+                            raise RuntimeError("time step underflow: the nonlinear solve keeps diverging")
                         continue
                     break
             self.engine.clamp_saturation()
