@@ -64,6 +64,17 @@ def _d(a):
     return a.ctypes.data_as(C.POINTER(C.c_double))
 
 
+def default_threads():
+    """Threads for the OpenMP loops: the CPUs this process may run on, at most 16 (the CPU share of a one-GPU box:
+    os.cpu_count() there reports the whole host, and 100+ pinned threads on a 16-CPU quota crawl); TP_CPU_THREADS
+    overrides."""
+    try:
+        n = len(os.sched_getaffinity(0))
+    except AttributeError:
+        n = os.cpu_count() or 1
+    return int(os.environ.get("TP_CPU_THREADS", min(n, 16)))
+
+
 class CPortEngine:
     def __init__(self, spec, opts=None):
         from ..engine import DEFAULT_OPTS
@@ -72,6 +83,9 @@ class CPortEngine:
         self.opts = dict(DEFAULT_OPTS)
         self.opts.update(opts or {})
         o = self.opts
+        if o.get("bjacobi_blocks") is not None:
+            from ..engine import blocks_to_tile
+            o["ilu_tile"] = blocks_to_tile(spec["n"], o["bjacobi_blocks"])
         if o.get("ilu_tile") is None:
             o["ilu_tile"] = (1 << 30, 32, 1) if int(spec["n"][2]) == 1 else (1 << 30, 8, 8)
         self.nph = int(spec["nphase"])
@@ -102,6 +116,7 @@ class CPortEngine:
             _d(f(kT if kT is not None else 0.0)), nsrc, cell.ctypes.data_as(C.POINTER(C.c_int64)),
             kind.ctypes.data_as(C.POINTER(C.c_int32)), cst.ctypes.data_as(C.POINTER(C.c_int32)), _d(wt), _d(bhp), _d(qmax),
             _d(WI), C.byref(self._o)))
+        self.set_threads(default_threads())
         self.last = {}
 
     def set_threads(self, n):

@@ -27,7 +27,33 @@ DEFAULT_OPTS = dict(
     schur_a11=False,
     amg_gather_cells=2000000,     # GPU multi-slab execution detail (same algebra): ignored here
     ilu_tile=None,          # None: (whole line, 8, 8) in 3-D, (whole line, 32, 1) in 2-D -- the GPU engine's default
+    bjacobi_blocks=None,    # -sub_1_pc_bjacobi_blocks: N boxes over the grid (same rule as the GPU engine, no lane limit)
 )
+
+
+def blocks_to_tile(n, nblocks):
+    """``-sub_1_pc_bjacobi_blocks N`` (tests/test_homo_wells.py:112,125 of the reference) -> the tile that cuts the grid
+    into N boxes, whole axis-0 lines first, then the most compact box (the GPU engine applies the same rule plus its
+    64-column limit per tile)."""
+    n0, n1, n2 = (int(v) for v in n)
+    best = None
+    for k2 in range(1, min(n2, nblocks) + 1):
+        if nblocks % k2:
+            continue
+        rem = nblocks//k2
+        for k1 in range(1, min(n1, rem) + 1):
+            if rem % k1 or rem//k1 > n0:
+                continue
+            k0 = rem//k1
+            t = (-(-n0//k0), -(-n1//k1), -(-n2//k2))
+            if (-(-n0//t[0]), -(-n1//t[1]), -(-n2//t[2])) != (k0, k1, k2):
+                continue
+            score = (k0 != 1, t[0]*t[1] + t[1]*t[2] + t[0]*t[2])
+            if best is None or score < best[0]:
+                best = (score, t)
+    if best is None:
+        raise ValueError("no tiling of %r into %d boxes" % (n, nblocks))
+    return best[1]
 
 
 class OracleEngine:
@@ -38,6 +64,8 @@ class OracleEngine:
         self.prob = Problem(spec)
         self.b = self.prob.b
         self.u = None
+        if self.opts.get("bjacobi_blocks") is not None:
+            self.opts["ilu_tile"] = blocks_to_tile(spec["n"], self.opts["bjacobi_blocks"])
         if self.opts.get("ilu_tile") is None:
             self.opts["ilu_tile"] = (1 << 30, 32, 1) if int(spec["n"][2]) == 1 else (1 << 30, 8, 8)
         self.pc = la.TwoStagePC(self.prob, self.opts)

@@ -335,6 +335,115 @@ class SemiAMG:
         return x
 
 
+class BlockSemiAMG(SemiAMG):
+    """System version of SemiAMG for the interleaved (p,T) operator of pc_cptramg[_QI|_TI] (twophase.py:552-566:
+    hypre BoomerAMG on Atilde_00 with the VectorFunctionSpace layout, ``vector=True`` :935-955).  hypre cannot be
+    reproduced; this is the build's own "unknown-based" system AMG on the same semicoarsening grids:
+      * every stencil entry is an nb x nb block, arrays (7, nb, nb, n2, n1, n0); vectors (nb, n2, n1, n0);
+      * interpolation per unknown q from its own diagonal block A^{qq} (weights w-_q, w+_q as in SemiAMG);  R = P^T;
+      * coarse block (q, r): rows combined with the restriction weights of q, columns along the coarsening axis
+        interpolated with the weights of r, the same lumped non-Galerkin 7-point formula block by block;
+      * smoother: damped block-Jacobi with the nb x nb diagonal blocks; dense solve on the coarsest grid."""
+
+    def __init__(self, n, strength, nb=2, **kw):
+        super().__init__(n, strength, **kw)
+        self.nb = nb
+
+    def bweights(self, A, a):
+        cross = [s for s in range(1, 7) if (s - 1) // 2 != a]
+        wm, wp = [], []
+        for q in range(self.nb):
+            c = A[0, q, q] + sum(A[s, q, q] for s in cross)
+            wm.append(-A[1 + 2 * a, q, q] / c)
+            wp.append(-A[2 + 2 * a, q, q] / c)
+        return np.array(wm), np.array(wp)
+
+    def bcoarsen(self, A, a, w):
+        ax = 2 - a
+        n = A.shape[3 + ax]
+        nc = (n + 1) // 2
+        wm, wp = w
+        ev = _axsl(ax, slice(0, n, 2))
+
+        def nb_(x, side):
+            out = np.zeros(x[ev].shape)
+            if side < 0:
+                out[_axsl(ax, slice(1, None))] = x[_axsl(ax, slice(1, n, 2))][_axsl(ax, slice(0, nc - 1))]
+            else:
+                src = x[_axsl(ax, slice(1, n, 2))]
+                out[_axsl(ax, slice(0, src.shape[ax]))] = src
+            return out
+        lo_s, hi_s = 1 + 2 * a, 2 + 2 * a
+        Ac = np.zeros((7, self.nb, self.nb) + A[0, 0, 0][ev].shape)
+        for q in range(self.nb):
+            Pm, Pp = nb_(wp[q], -1), nb_(wm[q], +1)          # row restriction weights of unknown q
+            for r in range(self.nb):
+                B = A[:, q, r]
+                rho = B.sum(axis=0)
+                Ac[lo_s, q, r] = B[lo_s][ev] * nb_(wm[r], -1)    # column interpolation weights of unknown r
+                Ac[hi_s, q, r] = B[hi_s][ev] * nb_(wp[r], +1)
+                for s in range(1, 7):
+                    if s in (lo_s, hi_s):
+                        continue
+                    Ac[s, q, r] = B[s][ev] + Pm * nb_(B[s], -1) + Pp * nb_(B[s], +1)
+                Ac[0, q, r] = -Ac[1:, q, r].sum(axis=0) + rho[ev] + Pm * nb_(rho, -1) + Pp * nb_(rho, +1)
+        return Ac
+
+    def setup(self, A):
+        self.levels = [self._store(A)]
+        self.W = []
+        for a in self.sched:
+            A_l = self.levels[-1]
+            w = tuple(self._store(v) for v in self.bweights(A_l, a))
+            self.levels.append(self._store(self.bcoarsen(A_l, a, w)))
+            self.W.append(w)
+        self.invD = []
+        for l in self.levels:
+            D = l[0].transpose(2, 3, 4, 0, 1)                       # (..., nb, nb)
+            self.invD.append(self._store(self.omega * np.linalg.inv(D).transpose(3, 4, 0, 1, 2)))
+        import scipy.sparse.linalg as spla
+        self.coarse = spla.splu(to_csr(self.levels[-1]).tocsc())
+        return self
+
+    def _bsmooth(self, lvl, b, x):
+        r = b - spmv_block(self.levels[lvl], x)
+        return x + np.einsum("qr...,r...->q...", self.invD[lvl], r)
+
+    def _each(self, fn, v, lvl, *a):
+        saveW = self.W[lvl]
+        out = []
+        for q in range(self.nb):
+            self.W[lvl] = (saveW[0][q], saveW[1][q])
+            out.append(fn(v[q], lvl, *a))
+        self.W[lvl] = saveW
+        return np.array(out)
+
+    def vcycle(self, b, lvl=0):
+        if lvl == len(self.levels) - 1:
+            nbk = b.shape[0]
+            xf = self.coarse.solve(b.reshape(nbk, -1).T.reshape(-1))       # cell-interleaved like to_csr
+            return xf.reshape(-1, nbk).T.reshape(b.shape)
+        ncell = b[0].size
+        if lvl < self.full_levels:
+            pre, post = self.nu, self.nu
+        else:
+            pre, post = self.coarse_pre, (self.tail_post if ncell <= 1024 else self.coarse_post)
+            if self.mid_skip and ncell > 1024 and (lvl - self.full_levels) % 2 == 1:
+                pre, post = 0, 0
+        if pre == 0:
+            x, r = np.zeros_like(b), b
+        else:
+            x = np.einsum("qr...,r...->q...", self.invD[lvl], b)
+            for _ in range(pre - 1):
+                x = self._bsmooth(lvl, b, x)
+            r = b - spmv_block(self.levels[lvl], x)
+        ec = self.vcycle(self._each(self.restrict, r, lvl), lvl + 1)
+        x = x + self._each(self.prolong, ec, lvl, b.shape[1:])
+        for _ in range(post):
+            x = self._bsmooth(lvl, b, x)
+        return x
+
+
 # ------------------------------------------------------------------ stage 1 (CPR / CPTR)
 def decouple(J, kind, primary):
     """Atilde = A_00 - D_0s D_ss^-1 A_s0 on the cell-interleaved stencil.
@@ -440,6 +549,8 @@ class TwoStagePC:
         self.amg_p = SemiAMG(n, st, **kw)
         self.amg_T = SemiAMG(n, [prob.G[a] if n[a] > 1 else 0.0 for a in range(3)], **kw) \
             if opts["pc"] in ("cptr", "fieldsplit_cd") else None
+        # pc_cptramg: ONE system V-cycle on the (p,T) 2x2-block operator (coarsening schedule of the pressure)
+        self.amg_pT = BlockSemiAMG(n, st, nb=2, **kw) if opts["pc"] == "cptramg" else None
         self.ilu = TiledILU0(shape, opts["ilu_tile"], self.slabs)
         self.vcycles = 0
 
@@ -457,6 +568,12 @@ class TwoStagePC:
             self.amg_p.setup(At[:, 0, 0])
             # K(S): the convection-diffusion operator S~, or (schur_precondition a11, twophase.py:598-616) A_11
             self.amg_T.setup(At[:, 1, 1] if o.get("schur_a11") else Sm)
+        elif o["pc"] == "cptramg":
+            # pc_cptramg[_QI|_TI] (twophase.py:552-566): CPTRStage1PC whose stage-1 solver is ONE AMG V-cycle on the
+            # interleaved (p,T) system Atilde_00 (preconditioners.py:1505-1543)
+            At, self.d = decouple(J, o["decoup"], [0, 1])
+            self.At = At
+            self.amg_pT.setup(At)
         elif o["pc"] == "fieldsplit_cd":
             # single-phase block preconditioner (singlephase.py:309-319): the same Schur FULL stage on the
             # undecoupled (p,T) system with the ConvDiffSchurPC operator (preconditioners.py:11-163); no stage 2
@@ -479,6 +596,11 @@ class TwoStagePC:
             else:
                 r = x[0] - self.d[0] * x[s]
             y[0] = self.amg_p.vcycle(r)
+            self.vcycles += 1
+        elif o["pc"] == "cptramg":
+            r0 = x[0] if self.d is None else x[0] - self.d[0] * x[s]
+            r1 = x[1] if self.d is None else x[1] - self.d[1] * x[s]
+            y[:2] = self.amg_pT.vcycle(np.array([r0, r1]))
             self.vcycles += 1
         else:
             r0 = x[0] if self.d is None else x[0] - self.d[0] * x[s]

@@ -156,3 +156,58 @@ def test_full_size_properties_c4():
     b = h.vec_get("b")
     assert np.linalg.norm(h.vec_get("Jd") - b) <= 1.5e-8*np.linalg.norm(b)
     h.close()
+
+
+def test_time_kernel_before_pc_setup_single_phase_fieldsplit():
+    """Regression (round-1 advisor): on a 2-field context tp_time_kernel used to allocate the scratch vector w3 with
+    b*ntot = 2 planes while the Schur stage writes a third one.  Timing a kernel BEFORE any pc_setup and then applying
+    the preconditioner must give the same result as a context that never called tp_time_kernel."""
+    from thermalporous_amd.engine import HipEngine
+    spec, u0, *_ = cases.c4_spe10_3d(Nx=9, Ny=11, Nz=7, nphase=1)
+    u = cases.perturbed_state(spec, seed=4, amp=0.3)
+    x = np.random.default_rng(5).standard_normal(u.shape)
+    res = []
+    for timed_first in (True, False):
+        h = HipEngine(spec, dict(pc="fieldsplit_cd"))
+        h.set_old(u0)
+        h.set_dt(4000.0)
+        h.set_state(u)
+        h.jacobian()
+        if timed_first:
+            for which in (0, 3, 5, 6):
+                assert h.time_kernel(which, 2) > 0.0
+            h.jacobian()
+        h.pc_setup()
+        h.vec_set("x", x)
+        h.pc_apply("x", "y")
+        res.append(h.vec_get("y"))
+        h.close()
+    assert rel2(res[0], res[1]) < 1e-13
+
+
+def test_time_kernel_pc_apply_after_a_solve():
+    """tp_time_kernel(which=4) right after Newton solves: the first capture of a NEW (input, output) hipGraph pair
+    after cached pairs have been replayed (the call that crashed once under rocprofv3) -- and the
+    captured application equals the eager one."""
+    from thermalporous_amd.engine import HipEngine
+    spec, u0, *_ = cases.c4_spe10_3d(Nx=12, Ny=20, Nz=10, nphase=2)
+    h = HipEngine(spec, dict(pc="cptr", ksp_rtol=1e-8, snes_max_it=25))
+    h.set_state(u0)
+    for dt in (8.0, 16.0):
+        h.set_old(None)
+        h.set_dt(dt)
+        assert h.newton_solve()["reason"] > 0
+    h.jacobian()
+    h.pc_setup()
+    for which in (0, 1, 2, 3, 4, 5, 6, 4):
+        assert h.time_kernel(which, 3) > 0.0
+    x = np.random.default_rng(6).standard_normal((3,) + spec["phi"].shape)
+    h.vec_set("x", x)
+    h.pc_apply("x", "y1")                 # captured
+    h.stage1_apply("x", "s")              # eager pieces: y = s + ILU(x - J s)
+    h.spmv("s", "Js")
+    h.vec_axpby("r", 1.0, "x", -1.0, "Js")
+    h.ilu_solve("r", "z")
+    h.vec_axpby("y2", 1.0, "s", 1.0, "z")
+    assert rel2(h.vec_get("y1"), h.vec_get("y2")) < 1e-12
+    h.close()

@@ -330,3 +330,42 @@ def test_convergence_error_is_raised_like_firedrake():
     m.start()
     with pytest.raises(exceptions.ConvergenceError):
         m.solver.solve()
+
+
+def test_bjacobi_blocks_option_maps_to_tiles_or_raises():
+    """``sub_1_pc_bjacobi_blocks`` (tests/test_homo_wells.py:112,125 of the reference) is consumed: N boxes over the grid.
+    The GPU engine realises it when a tile fits one wavefront (<= 64 columns) and raises otherwise; the oracle has no
+    limit (one block = whole-grid ILU(0))."""
+    from thermalporous_amd.engine import tiles_for_blocks
+    from oracle.engine import blocks_to_tile
+    assert tiles_for_blocks((400, 400, 1), 16) == (400, 25, 1)          # pc_cpr_bilu of test_homo_wells.py on N = 400
+    assert tiles_for_blocks((85, 60, 220), 224) == (85, 9, 7)
+    with pytest.raises(NotImplementedError):
+        tiles_for_blocks((400, 400, 1), 1)                               # 400 columns > one wavefront
+    with pytest.raises(NotImplementedError):
+        tiles_for_blocks((85, 60, 220), 1)
+    assert tiles_for_blocks((60, 8, 8), 1) == (60, 8, 8)
+    assert blocks_to_tile((400, 400, 1), 1) == (400, 400, 1)
+    assert blocks_to_tile((85, 60, 220), 1) == (85, 60, 220)
+    d = {"snes_type": "newtonls", "ksp_type": "fgmres", "pc_type": "composite", "pc_composite_type": "multiplicative",
+         "pc_composite_pcs": "python,bjacobi", "sub_0_pc_python_type": "thermalporous.preconditioners.CPRStage1PC",
+         "sub_0_cpr_stage1": {"ksp_type": "preonly", "pc_type": "hypre", "pc_hypre_type": "boomeramg",
+                              "pc_hypre_boomeramg_max_iter": 1},
+         "sub_1_pc_bjacobi_blocks": 16, "sub_1_sub_pc_type": "ilu", "sub_1_sub_pc_factor_levels": 0, "mat_type": "aij"}
+    assert engine_options(d, "Single phase")["bjacobi_blocks"] == 16
+    # keys that used to pass silently by prefix are now errors or checked values
+    with pytest.raises(NotImplementedError):
+        engine_options({**d, "snes_linesearch_type": "l2"}, "Single phase")
+    with pytest.raises(KeyError):
+        engine_options({**d, "sub_1_sub_pc_factor_fill": 2.0}, "Single phase")
+    with pytest.raises(NotImplementedError):
+        engine_options({**d, "sub_0_cpr_stage1_pc_hypre_boomeramg_strong_threshold": 0.5}, "Single phase")
+    with pytest.raises(NotImplementedError):        # PETSc's default side for gmres is LEFT
+        engine_options({**d, "ksp_type": "gmres"}, "Single phase")
+    # one block on a grid the oracle engine can take: whole-grid ILU(0)
+    spec, u0, p, g, c = cases.c1_homogeneous(N=10)
+    m = SinglePhase(g, c, p, end=1.0, maxdt=1.0, small_dt_start=False, solver_parameters={**d, "sub_1_pc_bjacobi_blocks": 1},
+                    filename=None, verbosity=False, _engine_factory=OracleEngine)
+    assert m.engine.opts["ilu_tile"] == (10, 10, 1)
+    m.solve()
+    assert m.failed_solves == 0

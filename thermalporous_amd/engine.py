@@ -73,6 +73,7 @@ DEFAULT_OPTS = dict(
     amg_gather_cells=2000000,
     schur_a11=False,
     ilu_tile=None,          # None: whole axis-0 lines x 8 x 8 columns (3-D), x 32 columns (2-D); see default_ilu_tile
+    bjacobi_blocks=None,    # -sub_1_pc_bjacobi_blocks N: N blocks over the whole grid (tiles_for_blocks); overrides ilu_tile
 )
 
 def default_ilu_tile(n):
@@ -80,6 +81,43 @@ def default_ilu_tile(n):
     3-D; 32 x 1 in 2-D (measured on C3 60x220: 64-wide tiles cost 123 wavefront steps for 60 cells of depth, 32-wide
     ones 91 steps and +0.5 % Krylov iterations)."""
     return (1 << 30, 32, 1) if int(n[2]) == 1 else (1 << 30, 8, 8)
+
+
+def tiles_for_blocks(n, nblocks, max_cols=64):
+    """Tile (t0, t1, t2) that cuts the grid n = (n0, n1, n2) into exactly `nblocks` boxes = bjacobi blocks
+    (``-sub_1_pc_bjacobi_blocks``, /root/reference/tests/test_homo_wells.py:112,125).  PETSc's blocks are contiguous row
+    ranges of its field-major DMPlex ordering, which has no counterpart here; the build's blocks are boxes of whole
+    cells, whole axis-0 lines when possible.  A GPU tile is swept by one wavefront: at most `max_cols` = 64 columns
+    (t1*t2); None lifts the limit (CPU oracle).  Raises NotImplementedError when no such tiling exists."""
+    n0, n1, n2 = (int(v) for v in n)
+    nblocks = int(nblocks)
+    if nblocks < 1:
+        raise ValueError("bjacobi_blocks must be >= 1")
+    best = None
+    for k2 in range(1, min(n2, nblocks) + 1):
+        if nblocks % k2:
+            continue
+        rem = nblocks//k2
+        for k1 in range(1, min(n1, rem) + 1):
+            if rem % k1:
+                continue
+            k0 = rem//k1
+            if k0 > n0:
+                continue
+            t = [-(-n0//k0), -(-n1//k1), -(-n2//k2)]
+            if (-(-n0//t[0]), -(-n1//t[1]), -(-n2//t[2])) != (k0, k1, k2):
+                continue
+            if max_cols is not None and t[1]*t[2] > max_cols:
+                continue
+            score = (k0 != 1, t[0]*t[1] + t[1]*t[2] + t[0]*t[2])      # whole lines first, then the most compact box
+            if best is None or score < best[0]:
+                best = (score, tuple(t))
+    if best is None:
+        raise NotImplementedError(
+            "sub_1_pc_bjacobi_blocks = %d cannot be realised on a %dx%dx%d grid with bjacobi tiles of at most %s columns "
+            "(one wavefront sweeps a tile; whole-grid ILU(0) needs n1*n2 <= 64 here).  Leave the key out for the "
+            "engine's default tiles, or pass ilu_tile." % (nblocks, n0, n1, n2, max_cols))
+    return best[1]
 
 
 _PC = {"cpr": 0, "cptr": 1, "fieldsplit_cd": 2}
@@ -125,6 +163,10 @@ class HipEngine:
         self.spec = spec
         self.opts = dict(DEFAULT_OPTS)
         self.opts.update(opts or {})
+        if self.opts.get("bjacobi_blocks") is not None:
+            if int(nranks) > 1:
+                raise EngineError("bjacobi_blocks counts blocks over the whole grid: set ilu_tile on multi-slab runs")
+            self.opts["ilu_tile"] = tiles_for_blocks(spec["n"], self.opts["bjacobi_blocks"], max_cols=64)
         if self.opts["ilu_tile"] is None:
             self.opts["ilu_tile"] = default_ilu_tile(spec["n"])
         self.nph = int(spec["nphase"])
