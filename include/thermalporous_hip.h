@@ -66,7 +66,9 @@ typedef struct tp_options {
     int32_t pc_kind;         /* 0 = pc_cpr (CPRStage1PC + bjacobi/ILU0), 1 = pc_cptr (CPTRStage1PC
                                 with fieldsplit Schur FULL, V(App), V(S~)), 2 = pc_fieldsplit_cd
                                 (single-phase: fieldsplit Schur FULL on (p,T) with V(App) and the
-                                ConvDiffSchurPC V(S~), no second stage; singlephase.py:309-319) */
+                                ConvDiffSchurPC V(S~), no second stage; singlephase.py:309-319),
+                                3 = pc_cptramg[_QI|_TI] (CPTRStage1PC with ONE system-AMG V-cycle on the 2x2-block
+                                (p,T) operator Atilde_00 + bjacobi/ILU0; twophase.py:552-566) */
     int32_t decoup;          /* 0 "No", 1 "QI", 2 "TI", 3 "QI_temp", 4 "TI_temp" (option key sub_0_cpr_decoup;
                                 the _temp variants decouple both T and S: two-phase pc_cpr only) */
     double  ksp_rtol, ksp_atol;
@@ -156,6 +158,16 @@ int tp_vec_copy_residual(tp_ctx *ctx, int32_t id);        /* vec <- R */
 
 /* operators (PETSc MatMult AIJ / PCApply in the reference: option dicts singlephase.py:303-354,
  * twophase.py:478-482,531-597) */
+/* PETSc Vec kernels of one Krylov iteration (SURVEY.md 8b minimum list; KSP fgmres, twophase.py:426-432):
+ *   tp_vec_create_batch  n vectors in ONE allocation (ids first..first+n-1): a Krylov basis
+ *   tp_vec_dot_batch     out[i] = <v_{first+i}, w>, i < n   (VecMDot: one pass over w, one host sync)
+ *   tp_vec_axpy_batch    w += sum_i coef[i] v_{first+i}     (VecMAXPY: one pass over w)
+ *   tp_vec_norm2         ||x||_2                            (VecNorm)
+ * Reductions run over owned cells only and are summed over the slabs (RCCL all-reduce) in multi-GPU runs. */
+int tp_vec_create_batch(tp_ctx *ctx, int32_t n, int32_t *first_id);
+int tp_vec_dot_batch(tp_ctx *ctx, int32_t first, int32_t n, int32_t w, double *out);
+int tp_vec_axpy_batch(tp_ctx *ctx, int32_t first, int32_t n, const double *coef, int32_t w);
+int tp_vec_norm2(tp_ctx *ctx, int32_t x, double *out);
 int tp_spmv(tp_ctx *ctx, int32_t x, int32_t y);            /* y = J x */
 int tp_pc_setup(tp_ctx *ctx);                              /* PCSetUp: decoupling, AMG setup, ILU factor */
 int tp_pc_apply(tp_ctx *ctx, int32_t x, int32_t y);        /* composite multiplicative (stage1, ILU0) */
@@ -164,6 +176,7 @@ int tp_stage1_apply(tp_ctx *ctx, int32_t x, int32_t y);    /* ....apply (precond
 int tp_ilu0_factor(tp_ctx *ctx);                           /* sub_1: bjacobi + ILU(0) numeric factorisation (singlephase.py:348-349) */
 int tp_ilu0_solve(tp_ctx *ctx, int32_t x, int32_t y);
 int tp_amg_setup(tp_ctx *ctx, int32_t which);              /* v_cycle dict (singlephase.py:303-307); 0: pressure operator, 1: S~ */
+/* which: 0 pressure hierarchy, 1 S~ hierarchy, 2 the (p,T) system hierarchy of pc_cptramg (fields 0,1 of b -> x) */
 int tp_amg_vcycle(tp_ctx *ctx, int32_t which, int32_t field_b, int32_t b, int32_t field_x, int32_t x);
 int tp_schur_apply(tp_ctx *ctx, int32_t x, int32_t y);     /* ConvDiffSchur*PC.apply: one V-cycle on S~, field 1 */
 

@@ -54,6 +54,11 @@ CASES = [
     ("c4_2ph_3d_cptr_a11", cases.c4_spe10_3d, dict(Nx=7, Ny=8, Nz=6, nphase=2), dict(pc="cptr", schur_a11=True)),
     ("c4_2ph_3d_cptrQI_a11", cases.c4_spe10_3d, dict(Nx=7, Ny=8, Nz=6, nphase=2), dict(pc="cptr", decoup="QI", schur_a11=True)),
     ("c4_1ph_3d_fs_a11", cases.c4_spe10_3d, dict(Nx=7, Ny=8, Nz=6, nphase=1), dict(pc="fieldsplit_cd", schur_a11=True)),
+    # pc_cptramg[_QI|_TI] (twophase.py:552-566): one system-AMG V-cycle on the 2x2-block (p,T) operator as stage 1
+    ("c4_2ph_3d_cptramg", cases.c4_spe10_3d, dict(Nx=7, Ny=13, Nz=9, nphase=2), dict(pc="cptramg")),
+    ("c4_2ph_3d_cptramg_QI", cases.c4_spe10_3d, dict(Nx=9, Ny=14, Nz=8, nphase=2), dict(pc="cptramg", decoup="QI")),
+    ("c4_2ph_3d_cptramg_TI", cases.c4_spe10_3d, dict(Nx=16, Ny=18, Nz=16, nphase=2), dict(pc="cptramg", decoup="TI", amg_full_levels=1)),
+    ("c3_2ph_2d_cptramg", cases.c3_spe10_2d, dict(Nx=14, Ny=19, nphase=2), dict(pc="cptramg", decoup="QI", ilu_tile=(1 << 30, 64, 1))),
     # single-phase block preconditioner pc_fieldsplit_cd (singlephase.py:309-319): ConvDiffSchurPC operator
     ("c4_1ph_3d_fscd", cases.c4_spe10_3d, dict(Nx=7, Ny=13, Nz=9, nphase=1), dict(pc="fieldsplit_cd")),
     ("c2_1ph_2d_fscd", cases.c3_spe10_2d, dict(Nx=14, Ny=19, nphase=1), dict(pc="fieldsplit_cd")),
@@ -117,6 +122,23 @@ def test_linear_stages_parity(name, builder, kw, opts):
     h.pc_setup()
     h.ilu_solve("x", "y")
     assert rel2(h.vec_get("y"), o.pc.ilu.solve(x)) < 1e-10
+    if opts["pc"] == "cptramg":
+        h.amg_vcycle(2, "x", 0, "y", 0)          # the system V-cycle on fields (p,T)
+        assert rel2(h.vec_get("y")[:2], o.pc.amg_pT.vcycle(x[:2])) < 1e-10
+        h.stage1_apply("x", "y")
+        assert rel2(h.vec_get("y"), o.pc.stage1(x)) < 1e-10
+        h.pc_apply("x", "y")
+        assert rel2(h.vec_get("y"), o.pc.apply(x)) < 1e-10
+        F = o.residual()
+        h.residual()
+        h.copy_residual_to("b")
+        its_h, reason_h, _ = h.fgmres("b", "d")
+        d_o, its_o, reason_o, _ = la.fgmres(lambda v: la.spmv_block(J, v), o.pc.apply, F, rtol=o.opts["ksp_rtol"],
+                                            maxit=o.opts["ksp_max_it"], restart=o.opts["ksp_restart"])
+        assert reason_h == reason_o == 2 and abs(its_h - its_o) <= 1, (its_h, its_o)
+        assert rel2(h.vec_get("d"), d_o) < 1e-6
+        h.close()
+        return
     h.amg_vcycle(0, "x", 0, "y", 0)
     # amg_single: both sides round the stored operators to fp32 identically; the double-precision
     # intermediates differ by FMA contraction before that rounding, so a few entries round differently
@@ -149,6 +171,7 @@ NEWTON = [
     ("c3", cases.c3_spe10_2d, dict(Nx=14, Ny=19, nphase=2), dict(pc="cptr", ksp_rtol=1e-8, snes_max_it=25, ilu_tile=(1 << 30, 64, 1)), 864.0),
     ("c4", cases.c4_spe10_3d, dict(Nx=7, Ny=13, Nz=9, nphase=2), dict(pc="cptr", ksp_rtol=1e-8, snes_max_it=25), 86.4),
     ("c4_1ph_fscd", cases.c4_spe10_3d, dict(Nx=7, Ny=13, Nz=9, nphase=1), dict(pc="fieldsplit_cd", ksp_rtol=1e-8), 864.0),
+    ("c4_cptramg_QI", cases.c4_spe10_3d, dict(Nx=7, Ny=13, Nz=9, nphase=2), dict(pc="cptramg", decoup="QI", ksp_rtol=1e-8, snes_max_it=25), 86.4),
 ]
 
 
@@ -170,4 +193,29 @@ def test_newton_parity(name, builder, kw, opts, dt):
         assert rel2(uh[0], uo[0]) < 1e-8 and rel2(uh[1], uo[1]) < 1e-8
         if o.b == 3:
             assert np.abs(uh[2] - uo[2]).max() < 1e-8
+    h.close()
+
+
+def test_exported_vector_ops():
+    """tp_vec_dot_batch / tp_vec_axpy_batch / tp_vec_norm2 (VecMDot, VecMAXPY, VecNorm of one Krylov iteration) vs numpy."""
+    from thermalporous_amd.engine import HipEngine
+    spec, u0, *_ = cases.c4_spe10_3d(Nx=9, Ny=14, Nz=8, nphase=2)
+    h = HipEngine(spec, dict(pc="cptr"))
+    rng = np.random.default_rng(4)
+    n = 5
+    V = rng.standard_normal((n, 3) + spec["phi"].shape)
+    w = rng.standard_normal((3,) + spec["phi"].shape)
+    h.vec_batch("v", n)
+    for i in range(n):
+        h.vec_set("v%d" % i, V[i])
+    h.vec_set("w", w)
+    d = h.dot_batch("v", n, "w")
+    assert np.allclose(d, [np.vdot(V[i], w) for i in range(n)], rtol=1e-12, atol=1e-9)
+    assert abs(h.norm2("w") - np.linalg.norm(w)) <= 1e-12*np.linalg.norm(w)
+    coef = rng.standard_normal(n)
+    h.axpy_batch("v", n, coef, "w")
+    assert rel2(h.vec_get("w"), w + np.tensordot(coef, V, axes=1)) < 1e-13
+    with pytest.raises(Exception):
+        h.vec("solo")
+        h._ck(h.lib.tp_vec_dot_batch(h.ctx, h.vec("solo"), 2, h.vec("w"), None))
     h.close()

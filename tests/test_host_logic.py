@@ -144,8 +144,11 @@ def test_solver_option_mapping_and_rejections():
     m8 = TwoPhase(g, WellCase(p2, g, well_case="test0", constant_rate=True), p2, solver_parameters="pc_cptr_a11", filename=None,
                   verbosity=False, _engine_factory=OracleEngine)
     assert m8.engine_opts["pc"] == "cptr" and m8.engine_opts["schur_a11"] is True and m2.engine_opts["schur_a11"] is False
+    m9 = TwoPhase(g, WellCase(p2, g, well_case="test0", constant_rate=True), p2, solver_parameters="pc_cptramg_QI", filename=None,
+                  verbosity=False, _engine_factory=OracleEngine)      # (:552-566) forces vector=True (:935-943)
+    assert m9.engine_opts["pc"] == "cptramg" and m9.engine_opts["decoup"] == "QI" and m9.vector and m9.i_S_o == 1
     with pytest.raises(NotImplementedError):
-        TwoPhase(g, c, p2, solver_parameters="pc_cptramg_QI", filename=None, _engine_factory=OracleEngine)
+        TwoPhase(g, c, p2, solver_parameters="pc_cptrlu", filename=None, _engine_factory=OracleEngine)
     # the pure-PETSc "*_gmres" emulations (twophase.py:619-699, singlephase.py:355-368) are the same algebra
     c2 = WellCase(p2, g, well_case="test0", constant_rate=True)
     m4 = TwoPhase(g, c2, p2, filename=None, verbosity=False, _engine_factory=OracleEngine)      # default preset (:930)
@@ -369,3 +372,26 @@ def test_bjacobi_blocks_option_maps_to_tiles_or_raises():
     assert m.engine.opts["ilu_tile"] == (10, 10, 1)
     m.solve()
     assert m.failed_solves == 0
+
+
+def test_cptramg_oracle_time_loop_and_vector_view():
+    """pc_cptramg_QI (twophase.py:552-566) drives a two-phase case to the same state as pc_cptr; with vector=True the
+    host view follows the reference's VectorFunctionSpace x V layout: u.dat.data = [pT (ncell x 2), S_o]."""
+    sols = []
+    for preset in ("pc_cptr", "pc_cptramg_QI"):
+        spec, u0, p, g, c = cases.c3_spe10_2d(12, 16, 2)
+        m = TwoPhase(g, c, p, end=0.004, maxdt=0.002, solver_parameters=preset, filename=None, verbosity=False,
+                     _engine_factory=OracleEngine)
+        m.solve()
+        assert m.failed_solves == 0
+        sols.append(m)
+    a, b = sols
+    assert b.vector and not a.vector
+    pT, S = b.u.dat.data_ro
+    assert pT.shape == (12*16, 2) and S.shape == (12*16,) and not pT.flags.writeable
+    ua = a.u.dat.data_ro
+    assert np.linalg.norm(pT[:, 0] - ua[0]) <= 1e-6*np.linalg.norm(ua[0])
+    assert np.linalg.norm(pT[:, 1] - ua[1]) <= 1e-6*np.linalg.norm(ua[1])
+    assert np.abs(S - ua[2]).max() < 1e-6
+    b.u.dat.data[b.i_S_o][...] = 0.5            # the entry the reference's time loop writes (thermalmodel.py:229)
+    assert np.all(b.u._store[2] == 0.5) and b.u.dev_stale

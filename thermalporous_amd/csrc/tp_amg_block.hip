@@ -1,0 +1,457 @@
+// System (2x2-block) semicoarsening AMG: the stage-1 solver of pc_cptramg[_QI|_TI].
+//
+// Reference: twophase.py:552-566 -- CPTRStage1PC (preconditioners.py:1243-1571) with ONE hypre BoomerAMG V-cycle on
+// the interleaved (p,T) operator Atilde_00 (VectorFunctionSpace layout, `vector=True` forced at twophase.py:935-955;
+// 2*i, 2*i+1 indexing preconditioners.py:1534-1536).  hypre is not reproducible; like the scalar hierarchy of
+// tp_amg.hip this is the build's own AMG, mirrored by oracle/linalg.py:BlockSemiAMG -- an "unknown-based" system AMG
+// on the same semicoarsening grids:
+//   * every stencil entry is an NB x NB block (7*NB*NB planes per level), vectors are NB planes;
+//   * interpolation per unknown q from its own diagonal block A^{qq} (weights w-_q, w+_q), R = P^T;
+//   * coarse block (q,r): rows combined with the restriction weights of q, columns along the coarsening axis
+//     interpolated with the weights of r -- the same lumped non-Galerkin 7-point formula block by block;
+//   * smoother: damped block-Jacobi with the NB x NB diagonal blocks; dense inverse (partial pivoting) on the coarsest
+//     grid; cycle shape and coarsening schedule are those of the pressure hierarchy (same options).
+// This is a "next" row of SURVEY.md 8f-3: straightforward thread-per-cell kernels (each HBM-bound: 28 operator
+// planes per sweep), no launch fusion or single-workgroup tail as in tp_amg.hip.  Multi-GPU: the hierarchy is built
+// on the gathered global grid and replicated (dist_levels = 0), as for small scalar hierarchies.
+#include "tp_common.hpp"
+#include <algorithm>
+
+namespace tp {
+
+struct BAmgLevel {
+    GridDev g;
+    DBuf<double> A;            // 7*NB*NB planes (levels >= 1; level 0 views the Jacobian / decoupled operator)
+    BStencil op;
+    DBuf<double> invD;         // NB*NB planes: omega * inverse of the diagonal block
+    DBuf<double> wm, wp;       // NB planes each
+    DBuf<double> b, x, x2, r, e;
+    int axis = -1;
+    int pre = 0, post = 0;
+};
+
+struct BAmg {
+    int nb = 2;
+    std::vector<BAmgLevel *> lv;
+    std::vector<int> sched;
+    DBuf<double> dense;        // [M | Minv] of the coarsest grid, (nb*ncoarse)^2 each
+    int ncoarse = 0;
+    ~BAmg() { for (auto *l : lv) delete l; }
+};
+
+static inline dim3 grid_for(long n, int bs = 256) { return dim3((unsigned)((n + bs - 1) / bs)); }
+
+template <int NB>
+struct BLevelDev {
+    GridDev g;
+    BStencil op;
+    const double *invD, *wm, *wp;
+    int axis;
+};
+
+__device__ __forceinline__ void b_ijk(const GridDev &g, long tid, int &i0, int &i1, int &i2) {
+    i2 = (int)(tid / g.np);
+    const int rem = (int)(tid - (long)i2 * g.np);
+    i1 = rem / g.n0;
+    i0 = rem - i1 * g.n0;
+}
+
+// ---- set-up -------------------------------------------------------------------------------------------
+template <int NB>
+__global__ void k_bamg_level(BLevelDev<NB> L, double omega, double *wm, double *wp, double *invD) {
+    const long tid = (long)blockIdx.x * blockDim.x + threadIdx.x;
+    if (tid >= L.g.nown) return;
+    const long c = L.g.np + tid, nt = L.g.ntot;
+    double D[NB][NB];
+#pragma unroll
+    for (int q = 0; q < NB; ++q)
+#pragma unroll
+        for (int r = 0; r < NB; ++r) D[q][r] = L.op.at(0, q, r)[c];
+    if (NB == 1) {
+        invD[c] = omega / D[0][0];
+    } else {
+        const double det = D[0][0] * D[NB - 1][NB - 1] - D[0][NB - 1] * D[NB - 1][0];
+        const double f = omega / det;
+        invD[(0 * NB + 0) * nt + c] = D[NB - 1][NB - 1] * f;
+        invD[(0 * NB + (NB - 1)) * nt + c] = -D[0][NB - 1] * f;
+        invD[((NB - 1) * NB + 0) * nt + c] = -D[NB - 1][0] * f;
+        invD[((NB - 1) * NB + (NB - 1)) * nt + c] = D[0][0] * f;
+    }
+    if (L.axis < 0) return;
+#pragma unroll
+    for (int q = 0; q < NB; ++q) {
+        double cs = 0.0;
+#pragma unroll
+        for (int s = 1; s < 7; ++s)
+            if ((s - 1) / 2 != L.axis) cs += L.op.at(s, q, q)[c];
+        const double cc = D[q][q] + cs;
+        wm[(long)q * nt + c] = -L.op.at(1 + 2 * L.axis, q, q)[c] / cc;
+        wp[(long)q * nt + c] = -L.op.at(2 + 2 * L.axis, q, q)[c] / cc;
+    }
+}
+
+template <int NB>
+__global__ void k_bamg_coarsen(BLevelDev<NB> L, GridDev gc, BStencil Ac) {
+    const long tid = (long)blockIdx.x * blockDim.x + threadIdx.x;
+    if (tid >= gc.nown) return;
+    const GridDev &gf = L.g;
+    const int a = L.axis;
+    int I[3];
+    b_ijk(gc, tid, I[0], I[1], I[2]);
+    const long cc = gc.np + tid;
+    int F[3] = {I[0], I[1], I[2]};
+    F[a] = 2 * I[a];
+    const int nfa = a == 0 ? gf.n0 : (a == 1 ? gf.n1 : gf.n2);
+    const long stride = a == 0 ? 1 : (a == 1 ? gf.n0 : gf.np);
+    const long f = gf.np + (long)F[0] + (long)gf.n0 * F[1] + gf.np * F[2];
+    const bool hm = F[a] - 1 >= 0, hp = F[a] + 1 < nfa;
+    const long gm = hm ? f - stride : f, gp = hp ? f + stride : f;
+    const long ntf = gf.ntot;
+#pragma unroll
+    for (int q = 0; q < NB; ++q) {
+        const double Pm = hm ? L.wp[(long)q * ntf + gm] : 0.0;       // row restriction weights of unknown q
+        const double Pp = hp ? L.wm[(long)q * ntf + gp] : 0.0;
+#pragma unroll
+        for (int r = 0; r < NB; ++r) {
+            const double Wm = hm ? L.wm[(long)r * ntf + gm] : 0.0;   // column interpolation weights of unknown r
+            const double Wp = hp ? L.wp[(long)r * ntf + gp] : 0.0;
+            double rho_f = 0.0, rho_m = 0.0, rho_p = 0.0, out[7], offsum = 0.0;
+#pragma unroll
+            for (int s = 0; s < 7; ++s) {
+                const double af = L.op.at(s, q, r)[f];
+                const double am = hm ? L.op.at(s, q, r)[gm] : 0.0, ap = hp ? L.op.at(s, q, r)[gp] : 0.0;
+                rho_f += af; rho_m += am; rho_p += ap;
+                if (s == 0) continue;
+                double v;
+                if (s == 1 + 2 * a) v = af * Wm;
+                else if (s == 2 + 2 * a) v = af * Wp;
+                else v = af + Pm * am + Pp * ap;
+                out[s] = v;
+                offsum += v;
+            }
+            out[0] = -offsum + rho_f + Pm * rho_m + Pp * rho_p;
+#pragma unroll
+            for (int s = 0; s < 7; ++s) Ac.at(s, q, r)[cc] = out[s];
+        }
+    }
+}
+
+// dense inverse of the coarsest block system (cell-interleaved unknowns i = cell*NB + q), Gauss-Jordan with partial
+// pivoting in one workgroup (the (p,T) diagonal blocks are not ordered by dominance)
+template <int NB>
+__global__ __launch_bounds__(256) void k_bamg_dense_inverse(BLevelDev<NB> L, int ncell, double *M, double *Minv) {
+    const int n = ncell * NB;
+    const GridDev &g = L.g;
+    __shared__ int s_piv;
+    __shared__ double s_val[256];
+    __shared__ int s_idx[256];
+    for (int e = threadIdx.x; e < n * n; e += blockDim.x) { M[e] = 0.0; Minv[e] = (e / n == e % n) ? 1.0 : 0.0; }
+    __syncthreads();
+    const long off[7] = {0, -1, 1, -(long)g.n0, (long)g.n0, -g.np, g.np};
+    for (int rc = threadIdx.x; rc < ncell; rc += blockDim.x) {
+        int i0, i1, i2;
+        b_ijk(g, rc, i0, i1, i2);
+        const long c = g.np + rc;
+        const bool has[7] = {true, i0 > 0, i0 < g.n0 - 1, i1 > 0, i1 < g.n1 - 1, i2 > 0, i2 < g.n2 - 1};
+        for (int s = 0; s < 7; ++s)
+            if (has[s])
+                for (int q = 0; q < NB; ++q)
+                    for (int r = 0; r < NB; ++r)
+                        M[(long)(rc * NB + q) * n + (long)(rc + off[s]) * NB + r] += L.op.at(s, q, r)[c];
+    }
+    __syncthreads();
+    for (int p = 0; p < n; ++p) {
+        // pivot search over rows >= p
+        double best = -1.0;
+        int bi = p;
+        for (int r = p + threadIdx.x; r < n; r += blockDim.x) {
+            const double v = fabs(M[(long)r * n + p]);
+            if (v > best) { best = v; bi = r; }
+        }
+        s_val[threadIdx.x] = best;
+        s_idx[threadIdx.x] = bi;
+        __syncthreads();
+        if (threadIdx.x == 0) {
+            double bv = -1.0;
+            int bb = p;
+            for (int t = 0; t < (int)blockDim.x; ++t)
+                if (s_val[t] > bv || (s_val[t] == bv && s_idx[t] < bb)) { bv = s_val[t]; bb = s_idx[t]; }
+            s_piv = bb;
+        }
+        __syncthreads();
+        const int pr = s_piv;
+        if (pr != p)
+            for (int e = threadIdx.x; e < n; e += blockDim.x) {
+                double t = M[(long)p * n + e]; M[(long)p * n + e] = M[(long)pr * n + e]; M[(long)pr * n + e] = t;
+                t = Minv[(long)p * n + e]; Minv[(long)p * n + e] = Minv[(long)pr * n + e]; Minv[(long)pr * n + e] = t;
+            }
+        __syncthreads();
+        const double piv = M[(long)p * n + p];
+        __syncthreads();
+        for (int e = threadIdx.x; e < n; e += blockDim.x) { M[(long)p * n + e] /= piv; Minv[(long)p * n + e] /= piv; }
+        __syncthreads();
+        for (int e = threadIdx.x; e < n * n; e += blockDim.x) {
+            const int r = e / n, q = e % n;
+            if (r == p) continue;
+            const double fct = M[(long)r * n + p];
+            Minv[(long)r * n + q] -= fct * Minv[(long)p * n + q];
+            if (q != p) M[(long)r * n + q] -= fct * M[(long)p * n + q];
+        }
+        __syncthreads();
+        for (int r = threadIdx.x; r < n; r += blockDim.x)
+            if (r != p) M[(long)r * n + p] = 0.0;
+        __syncthreads();
+    }
+}
+
+// e = Minv b on the coarsest grid (vectors NB planes of the level, unknowns cell-interleaved in the dense matrix)
+template <int NB>
+__global__ __launch_bounds__(256) void k_bamg_coarse_apply(GridDev g, int ncell, const double *Minv, const double *b,
+                                                           double *e) {
+    const int n = ncell * NB;
+    for (int i = threadIdx.x; i < n; i += blockDim.x) {
+        double s = 0.0;
+        for (int j = 0; j < n; ++j) s += Minv[(long)i * n + j] * b[(long)(j % NB) * g.ntot + g.np + j / NB];
+        e[(long)(i % NB) * g.ntot + g.np + i / NB] = s;
+    }
+}
+
+// ---- cycle kernels -------------------------------------------------------------------------------------
+// (b - A x)_q at cell c
+template <int NB>
+__device__ __forceinline__ void b_resid(const BLevelDev<NB> &L, const double *b, const double *x, long c, double (&r)[NB]) {
+    const GridDev &g = L.g;
+    const long off[7] = {0, -1, 1, -(long)g.n0, (long)g.n0, -g.np, g.np};
+    const long nt = g.ntot;
+#pragma unroll
+    for (int q = 0; q < NB; ++q) r[q] = b[(long)q * nt + c];
+#pragma unroll
+    for (int s = 0; s < 7; ++s) {
+        double xv[NB];
+#pragma unroll
+        for (int k = 0; k < NB; ++k) xv[k] = x[(long)k * nt + c + off[s]];
+#pragma unroll
+        for (int q = 0; q < NB; ++q)
+#pragma unroll
+            for (int k = 0; k < NB; ++k) r[q] -= L.op.at(s, q, k)[c] * xv[k];
+    }
+}
+
+// out = invD b (first sweep from a zero guess) | out = x + invD (b - A x)
+template <int NB, bool FIRST>
+__global__ __launch_bounds__(256) void k_bamg_smooth(BLevelDev<NB> L, const double *b, const double *x, double *out) {
+    const long tid = xcd_tid();
+    if (tid >= L.g.nown) return;
+    const long c = L.g.np + tid, nt = L.g.ntot;
+    double r[NB];
+    if (FIRST) {
+#pragma unroll
+        for (int q = 0; q < NB; ++q) r[q] = b[(long)q * nt + c];
+    } else {
+        b_resid<NB>(L, b, x, c, r);
+    }
+#pragma unroll
+    for (int q = 0; q < NB; ++q) {
+        double s = FIRST ? 0.0 : x[(long)q * nt + c];
+#pragma unroll
+        for (int k = 0; k < NB; ++k) s += L.invD[(long)(q * NB + k) * nt + c] * r[k];
+        out[(long)q * nt + c] = s;
+    }
+}
+
+template <int NB>
+__global__ __launch_bounds__(256) void k_bamg_resid(BLevelDev<NB> L, const double *b, const double *x, double *r) {
+    const long tid = xcd_tid();
+    if (tid >= L.g.nown) return;
+    const long c = L.g.np + tid;
+    double v[NB];
+    b_resid<NB>(L, b, x, c, v);
+#pragma unroll
+    for (int q = 0; q < NB; ++q) r[(long)q * L.g.ntot + c] = v[q];
+}
+
+template <int NB>
+__global__ __launch_bounds__(256) void k_bamg_restrict(BLevelDev<NB> Lf, GridDev gc, const double *r, double *rc) {
+    const long tid = xcd_tid();
+    if (tid >= gc.nown) return;
+    const GridDev &gf = Lf.g;
+    const int a = Lf.axis;
+    int I[3];
+    b_ijk(gc, tid, I[0], I[1], I[2]);
+    int F[3] = {I[0], I[1], I[2]};
+    F[a] = 2 * I[a];
+    const int nfa = a == 0 ? gf.n0 : (a == 1 ? gf.n1 : gf.n2);
+    const long stride = a == 0 ? 1 : (a == 1 ? gf.n0 : gf.np);
+    const long f = gf.np + (long)F[0] + (long)gf.n0 * F[1] + gf.np * F[2];
+    const bool hm = F[a] - 1 >= 0, hp = F[a] + 1 < nfa;
+    const long fm = hm ? f - stride : f, fp = hp ? f + stride : f;
+#pragma unroll
+    for (int q = 0; q < NB; ++q) {
+        const long o = (long)q * gf.ntot;
+        double v = r[o + f];
+        v += hp ? Lf.wm[o + fp] * r[o + fp] : 0.0;       // (order of SemiAMG.restrict: right F point first)
+        v += hm ? Lf.wp[o + fm] * r[o + fm] : 0.0;
+        rc[(long)q * gc.ntot + gc.np + tid] = v;
+    }
+}
+
+// x (+)= P ec
+template <int NB>
+__global__ __launch_bounds__(256) void k_bamg_prolong(BLevelDev<NB> Lf, GridDev gc, const double *ec, const double *xin,
+                                                      double *xout) {
+    const long tid = xcd_tid();
+    if (tid >= Lf.g.nown) return;
+    const GridDev &g = Lf.g;
+    const int a = Lf.axis;
+    int i[3];
+    b_ijk(g, tid, i[0], i[1], i[2]);
+    const int Fa = i[a], Ia = Fa >> 1;
+    int I[3] = {i[0], i[1], i[2]};
+    I[a] = Ia;
+    const long ci = gc.np + (long)I[0] + (long)gc.n0 * I[1] + gc.np * I[2];
+    const long cs = a == 0 ? 1 : (a == 1 ? gc.n0 : gc.np);
+    const int nca = a == 0 ? gc.n0 : (a == 1 ? gc.n1 : gc.n2);
+    const long c = g.np + tid;
+    const bool isF = Fa & 1, hasR = isF && (Ia + 1 < nca);
+#pragma unroll
+    for (int q = 0; q < NB; ++q) {
+        const double e0 = ec[(long)q * gc.ntot + ci], e1 = ec[(long)q * gc.ntot + (hasR ? ci + cs : ci)];
+        const double v = isF ? Lf.wm[(long)q * g.ntot + c] * e0 + (hasR ? Lf.wp[(long)q * g.ntot + c] * e1 : 0.0) : e0;
+        xout[(long)q * g.ntot + c] = (xin ? xin[(long)q * g.ntot + c] : 0.0) + v;
+    }
+}
+
+// ---- host ----------------------------------------------------------------------------------------------
+template <int NB>
+static BLevelDev<NB> bdev(const BAmgLevel *L) {
+    BLevelDev<NB> d;
+    d.g = L->g; d.op = L->op; d.invD = L->invD.p; d.wm = L->wm.p; d.wp = L->wp.p; d.axis = L->axis;
+    return d;
+}
+
+void bamg_build(tp_ctx *c, BAmg *&amg, const GridDev &g0, const double strength[3]) {
+    delete amg;
+    amg = new BAmg();
+    c->graph_epoch++;
+    const int NB = amg->nb;
+    int n[3] = {g0.n0, g0.n1, g0.n2};
+    double s[3];
+    for (int a = 0; a < 3; ++a) s[a] = n[a] > 1 ? strength[a] : -1.0;
+    while ((long)n[0] * n[1] * n[2] > std::max(1, c->opt.amg_min_cells) && amg->sched.size() < 40) {
+        int best = -1;
+        for (int a = 0; a < 3; ++a)
+            if (n[a] > 1 && (best < 0 || s[a] > s[best])) best = a;
+        if (best < 0) break;
+        amg->sched.push_back(best);
+        n[best] = (n[best] + 1) / 2;
+        for (int q = 0; q < 3; ++q) s[q] = (q == best) ? s[q] * 0.5 : s[q] * 2.0;
+    }
+    int m[3] = {g0.n0, g0.n1, g0.n2};
+    const int nu = std::max(1, c->opt.amg_nu);
+    for (size_t l = 0; l <= amg->sched.size(); ++l) {
+        BAmgLevel *L = new BAmgLevel();
+        L->g = make_grid(m[0], m[1], m[2], m[2], 0);
+        const size_t nt = (size_t)L->g.ntot;
+        if (l > 0) {
+            L->A.alloc(7 * NB * NB * nt);
+            L->op.base = L->A.p; L->op.ss = (long)NB * NB * nt; L->op.rs = (long)NB * nt; L->op.cs = (long)nt;
+        }
+        L->invD.alloc(NB * NB * nt);
+        L->b.alloc(NB * nt); L->x.alloc(NB * nt); L->x2.alloc(NB * nt); L->r.alloc(NB * nt); L->e.alloc(NB * nt);
+        // cycle shape: the rules of tp_amg.hip:dev_of (mirrored by oracle/linalg.py)
+        const bool full = (int)l < c->opt.amg_full_levels;
+        const bool small = L->g.np * (long)L->g.gn2 <= 1024;
+        L->pre = full ? nu : std::max(0, c->opt.amg_coarse_pre);
+        L->post = full ? nu : std::max(1, small ? c->opt.amg_tail_post : c->opt.amg_coarse_post);
+        if (c->opt.amg_mid_skip && !full && !small && (((int)l - c->opt.amg_full_levels) & 1)) { L->pre = 0; L->post = 0; }
+        if (l < amg->sched.size()) {
+            L->axis = amg->sched[l];
+            L->wm.alloc(NB * nt); L->wp.alloc(NB * nt);
+            m[L->axis] = (m[L->axis] + 1) / 2;
+        }
+        amg->lv.push_back(L);
+    }
+    amg->ncoarse = (int)amg->lv.back()->g.nown;
+    TP_REQUIRE(amg->ncoarse * NB <= 2048, "coarsest system-AMG grid too large for the dense solve");
+    const size_t nd = (size_t)amg->ncoarse * NB;
+    amg->dense.alloc(2 * nd * nd);
+}
+
+void bamg_setup(tp_ctx *c, BAmg *amg, const BStencil &A0) {
+    constexpr int NB = 2;
+    TP_REQUIRE(amg->nb == NB, "system AMG is built for 2x2 blocks");
+    amg->lv[0]->op = A0;
+    for (size_t l = 0; l < amg->lv.size(); ++l) {
+        BAmgLevel *L = amg->lv[l];
+        const BLevelDev<NB> Ld = bdev<NB>(L);
+        hipLaunchKernelGGL(k_bamg_level<NB>, grid_for(L->g.nown), dim3(256), 0, c->stream, Ld, c->opt.amg_omega, L->wm.p,
+                           L->wp.p, L->invD.p);
+        if (L->axis >= 0) {
+            BAmgLevel *Lc = amg->lv[l + 1];
+            hipLaunchKernelGGL(k_bamg_coarsen<NB>, grid_for(Lc->g.nown), dim3(256), 0, c->stream, Ld, Lc->g, Lc->op);
+        }
+    }
+    BAmgLevel *Lc = amg->lv.back();
+    const size_t nd = (size_t)amg->ncoarse * NB;
+    hipLaunchKernelGGL(k_bamg_dense_inverse<NB>, dim3(1), dim3(256), 0, c->stream, bdev<NB>(Lc), amg->ncoarse, amg->dense.p,
+                       amg->dense.p + nd * nd);
+    TP_HIP(hipGetLastError());
+}
+
+// x = V-cycle(b): b, x are NB planes with the stride of level 0 (= ntot of the grid the hierarchy was built on)
+void bamg_vcycle(tp_ctx *c, BAmg *amg, const double *b, double *x) {
+    constexpr int NB = 2;
+    const int nlev = (int)amg->lv.size();
+    const dim3 bl(256);
+    std::vector<double *> xs(nlev, nullptr);
+    const size_t nd = (size_t)amg->ncoarse * NB;
+    for (int l = 0; l < nlev - 1; ++l) {
+        BAmgLevel *L = amg->lv[l], *Lc = amg->lv[l + 1];
+        const BLevelDev<NB> Ld = bdev<NB>(L);
+        const double *bl_ = (l == 0) ? b : L->b.p;
+        const dim3 gr = xcd_grid(L->g.nown);
+        const double *res = bl_;
+        if (L->pre > 0) {
+            double *cur = L->x.p, *oth = L->x2.p;
+            hipLaunchKernelGGL((k_bamg_smooth<NB, true>), gr, bl, 0, c->stream, Ld, bl_, (const double *)nullptr, cur);
+            for (int k = 1; k < L->pre; ++k) {
+                hipLaunchKernelGGL((k_bamg_smooth<NB, false>), gr, bl, 0, c->stream, Ld, bl_, (const double *)cur, oth);
+                std::swap(cur, oth);
+            }
+            xs[l] = cur;
+            hipLaunchKernelGGL(k_bamg_resid<NB>, gr, bl, 0, c->stream, Ld, bl_, (const double *)cur, L->r.p);
+            res = L->r.p;
+        }
+        hipLaunchKernelGGL(k_bamg_restrict<NB>, xcd_grid(Lc->g.nown), bl, 0, c->stream, Ld, Lc->g, res, Lc->b.p);
+    }
+    {
+        BAmgLevel *Lc = amg->lv[nlev - 1];
+        const double *bc = (nlev == 1) ? b : Lc->b.p;
+        double *ec = (nlev == 1) ? x : Lc->e.p;
+        hipLaunchKernelGGL(k_bamg_coarse_apply<NB>, dim3(1), dim3(256), 0, c->stream, Lc->g, amg->ncoarse,
+                           (const double *)(amg->dense.p + nd * nd), bc, ec);
+    }
+    for (int l = nlev - 2; l >= 0; --l) {
+        BAmgLevel *L = amg->lv[l], *Lc = amg->lv[l + 1];
+        const BLevelDev<NB> Ld = bdev<NB>(L);
+        const double *bl_ = (l == 0) ? b : L->b.p;
+        double *out = (l == 0) ? x : L->e.p;
+        const dim3 gr = xcd_grid(L->g.nown);
+        // x <- x + P ec into a buffer that is not the final output unless no post-smoothing follows
+        double *dst = (L->post == 0) ? out : (xs[l] == L->x.p ? L->x2.p : L->x.p);
+        hipLaunchKernelGGL(k_bamg_prolong<NB>, gr, bl, 0, c->stream, Ld, Lc->g, (const double *)Lc->e.p, (const double *)xs[l], dst);
+        double *src = dst;
+        for (int k = 0; k < L->post; ++k) {
+            dst = (k == L->post - 1) ? out : (src == L->x.p ? L->x2.p : L->x.p);
+            hipLaunchKernelGGL((k_bamg_smooth<NB, false>), gr, bl, 0, c->stream, Ld, bl_, (const double *)src, dst);
+            src = dst;
+        }
+    }
+    TP_HIP(hipGetLastError());
+}
+
+void bamg_destroy(BAmg *amg) { delete amg; }
+
+int bamg_levels(const BAmg *amg) { return (int)amg->lv.size(); }
+
+}  // namespace tp

@@ -200,6 +200,7 @@ tp_ctx::~tp_ctx() {
     for (auto *v : vecs) delete v;
     delete amg_p;
     delete amg_T;
+    if (bamg) tp::bamg_destroy(bamg);
     for (auto &gph : pc_graphs) (void)hipGraphExecDestroy(gph.exec);
     if (comm) ncclCommDestroy((ncclComm_t)comm);
     if (ev0) (void)hipEventDestroy(ev0);
@@ -307,11 +308,17 @@ int tp_set_options(tp_ctx *c, const tp_options *opt) {
     TP_REQUIRE(c && opt, "null argument");
     const bool tile_changed = opt->ilu_t1 != c->opt.ilu_t1 || opt->ilu_t2 != c->opt.ilu_t2 || opt->ilu_t0 != c->opt.ilu_t0;
     const bool amg_changed = opt->amg_min_cells != c->opt.amg_min_cells || opt->pc_kind != c->opt.pc_kind ||
+                             opt->amg_nu != c->opt.amg_nu || opt->amg_full_levels != c->opt.amg_full_levels ||
+                             opt->amg_coarse_pre != c->opt.amg_coarse_pre || opt->amg_coarse_post != c->opt.amg_coarse_post ||
+                             opt->amg_tail_post != c->opt.amg_tail_post || opt->amg_mid_skip != c->opt.amg_mid_skip ||
                              opt->amg_single != c->opt.amg_single || opt->amg_gather_cells != c->opt.amg_gather_cells ||
                              opt->schur_a11 != c->opt.schur_a11;
     c->opt = *opt;
     if (tile_changed) c->ilu.slots = 0;
-    if (amg_changed) { delete c->amg_p; c->amg_p = nullptr; delete c->amg_T; c->amg_T = nullptr; }
+    if (amg_changed) {
+        delete c->amg_p; c->amg_p = nullptr; delete c->amg_T; c->amg_T = nullptr;
+        if (c->bamg) { bamg_destroy(c->bamg); c->bamg = nullptr; }
+    }
     if (schur_of(*opt) && c->Sm.n == 0) c->Sm.alloc((size_t)7 * c->g.ntot);
     c->pc_ready = false;
     c->graph_epoch++;            // any option may change the captured kernel sequence: drop the pc_apply graphs
@@ -398,6 +405,7 @@ int tp_finalize_fields(tp_ctx *c) {
     c->fields_ready = true;
     delete c->amg_p; c->amg_p = nullptr;
     delete c->amg_T; c->amg_T = nullptr;
+    if (c->bamg) { bamg_destroy(c->bamg); c->bamg = nullptr; }
     c->pc_ready = false;
     c->graph_epoch++;
     TP_API_END
@@ -552,6 +560,60 @@ int tp_vec_create(tp_ctx *c, int32_t *id) {
     TP_API_END
 }
 
+int tp_vec_create_batch(tp_ctx *c, int32_t n, int32_t *first_id) {
+    TP_API_BEGIN
+    TP_REQUIRE(c && n >= 1 && first_id, "bad arguments");
+    const size_t nv = (size_t)c->b * c->g.ntot;
+    auto *owner = new DBuf<double>();
+    owner->alloc(nv * (size_t)n);                   // vector 0 of the batch owns the allocation
+    DBuf<double> *first = new DBuf<double>();
+    first->p = owner->p; first->n = nv; first->owned = true;
+    owner->p = nullptr; owner->n = 0;
+    delete owner;
+    c->vecs.push_back(first);
+    *first_id = (int32_t)c->vecs.size() - 1;
+    for (int i = 1; i < n; ++i) {
+        auto *v = new DBuf<double>();
+        v->view(first->p + (size_t)i * nv, nv);
+        c->vecs.push_back(v);
+    }
+    TP_API_END
+}
+
+// ids first..first+n-1 must be consecutive vectors of one batch (one allocation, stride b*ntot)
+static const double *batch_base(tp_ctx *c, int32_t first, int32_t n) {
+    const size_t nv = (size_t)c->b * c->g.ntot;
+    const double *base = vec_of(c, first).p;
+    for (int i = 1; i < n; ++i)
+        TP_REQUIRE(vec_of(c, first + i).p == base + (size_t)i * nv, "vectors are not consecutive members of one batch "
+                   "(tp_vec_create_batch)");
+    return base;
+}
+
+int tp_vec_dot_batch(tp_ctx *c, int32_t first, int32_t n, int32_t w, double *out) {
+    TP_API_BEGIN
+    TP_REQUIRE(c && n >= 1 && out, "bad arguments");
+    const double *V = batch_base(c, first, n);
+    multi_dot(c, c->b, V, (long)c->b * c->g.ntot, n, vec_of(c, w).p, nullptr, out);
+    TP_API_END
+}
+
+int tp_vec_axpy_batch(tp_ctx *c, int32_t first, int32_t n, const double *coef, int32_t w) {
+    TP_API_BEGIN
+    TP_REQUIRE(c && n >= 1 && coef, "bad arguments");
+    const double *V = batch_base(c, first, n);
+    TP_REQUIRE(w < first || w >= first + n, "w must not be a member of the batch");
+    multi_axpy(c, c->b, V, (long)c->b * c->g.ntot, n, coef, 1.0, vec_of(c, w).p);
+    TP_API_END
+}
+
+int tp_vec_norm2(tp_ctx *c, int32_t x, double *out) {
+    TP_API_BEGIN
+    TP_REQUIRE(c && out, "bad arguments");
+    *out = norm2(c, c->b, vec_of(c, x).p);
+    TP_API_END
+}
+
 int tp_vec_set(tp_ctx *c, int32_t id, const double *host) {
     TP_API_BEGIN
     DBuf<double> &v = vec_of(c, id);
@@ -634,6 +696,12 @@ int tp_amg_setup(tp_ctx *c, int32_t which) {
 int tp_amg_vcycle(tp_ctx *c, int32_t which, int32_t field_b, int32_t b, int32_t field_x, int32_t x) {
     TP_API_BEGIN
     TP_REQUIRE(c->pc_ready, "AMG not set up");
+    if (which == 2) {       // pc_cptramg: the system V-cycle on fields (0,1) of b -> fields (0,1) of x
+        TP_REQUIRE(c->bamg && !c->dist, "system AMG not set up (pc_cptramg, single slab)");
+        TP_REQUIRE(b != x && field_b == 0 && field_x == 0, "system V-cycle: fields (0,1) of two different vectors");
+        bamg_vcycle(c, c->bamg, vec_of(c, b).p, vec_of(c, x).p);
+        return 0;
+    }
     Amg *amg = which == 0 ? c->amg_p : c->amg_T;
     TP_REQUIRE(amg, "this AMG hierarchy does not exist for the selected preconditioner");
     TP_REQUIRE(!c->dist || amg->dist_levels > 0, "tp_amg_vcycle works on slab vectors: not available when the hierarchy is replicated on the gathered global grid");
@@ -684,6 +752,7 @@ int tp_time_kernel(tp_ctx *c, int32_t which, int32_t reps, double *ms_avg) {
             case 0: spmv_block(c, c->J.p, c->R.p, c->w2.p); break;
             case 1: ilu_solve(c, c->R.p, c->w2.p, nullptr); break;
             case 2:
+                if (sysamg_of(c->opt)) { TP_REQUIRE(!c->dist, "single slab only"); bamg_vcycle(c, c->bamg, c->R.p, c->w2.p); break; }
                 if (c->dist && c->amg_p->dist_levels == 0) amg_vcycle(c, c->amg_p, c->gvec.p, c->gvec.p + 2 * c->gfull.ntot);   // global-grid buffers
                 else amg_vcycle(c, c->amg_p, c->R.p, c->w2.p);
                 break;
@@ -707,6 +776,12 @@ int tp_time_kernel(tp_ctx *c, int32_t which, int32_t reps, double *ms_avg) {
 
 int tp_amg_info(tp_ctx *c, int32_t which, int32_t *nlevels, double *op_complexity) {
     TP_API_BEGIN
+    if (which == 2) {
+        TP_REQUIRE(c->bamg, "system AMG hierarchy not built");
+        if (nlevels) *nlevels = bamg_levels(c->bamg);
+        if (op_complexity) *op_complexity = 0.0;
+        return 0;
+    }
     Amg *amg = which == 0 ? c->amg_p : c->amg_T;
     TP_REQUIRE(amg, "AMG hierarchy not built");
     if (nlevels) *nlevels = (int)amg->lv.size();

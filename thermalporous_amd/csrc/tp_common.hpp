@@ -68,10 +68,11 @@ inline dim3 xcd_grid(long n, int bs = 256) {
     return dim3((unsigned)(((nb + 7) / 8) * 8));
 }
 
-// pc_kind: 0 pc_cpr, 1 pc_cptr, 2 pc_fieldsplit_cd.  The last two run the fieldsplit-Schur-FULL stage on (p,T)
-// and need the S~ operator from the assembly.
+// pc_kind: 0 pc_cpr, 1 pc_cptr, 2 pc_fieldsplit_cd, 3 pc_cptramg.  1 and 2 run the fieldsplit-Schur-FULL stage on
+// (p,T) and need the S~ operator from the assembly; 3 runs ONE system-AMG V-cycle on the 2x2-block (p,T) operator.
 inline int npri_of(const tp_options &o) { return o.pc_kind >= 1 ? 2 : 1; }
-inline bool schur_of(const tp_options &o) { return o.pc_kind >= 1; }
+inline bool schur_of(const tp_options &o) { return o.pc_kind == 1 || o.pc_kind == 2; }
+inline bool sysamg_of(const tp_options &o) { return o.pc_kind == 3; }
 
 // Scalar 7-point stencil operator: slot s lives at base + s*slot_stride (doubles).
 struct Stencil {
@@ -80,6 +81,15 @@ struct Stencil {
     __host__ __device__ const double *slot(int s) const { return base + (long)s * slot_stride; }
     __host__ __device__ double *slot(int s) { return base + (long)s * slot_stride; }
 };
+
+// Block 7-point stencil operator (system AMG): block (q,r) of slot s lives at base + s*ss + q*rs + r*cs.
+struct BStencil {
+    double *base = nullptr;
+    long ss = 0, rs = 0, cs = 0;
+    __host__ __device__ const double *at(int s, int q, int r) const { return base + s * ss + q * rs + r * cs; }
+    __host__ __device__ double *at(int s, int q, int r) { return base + s * ss + q * rs + r * cs; }
+};
+struct BAmg;
 
 // Derived closure constants (device copy of tp_params + precomputed factors).
 struct DevPrm {
@@ -187,6 +197,8 @@ struct tp_ctx {
     tp::DBuf<double> dcoef;       // decoupling coefficients d_q per cell (nprimary planes)
     tp::Stencil opA00, opA01, opA10;   // views used by stage 1
     tp::Amg *amg_p = nullptr, *amg_T = nullptr;
+    tp::BAmg *bamg = nullptr;          // pc_cptramg: system AMG on the (p,T) blocks (tp_amg_block.hip)
+    tp::DBuf<double> gAt;              // multi-GPU pc_cptramg: the 28 operator planes gathered on the global grid
     tp::IluData ilu;
     // FGMRES workspace
     tp::DBuf<double> V, Z, gs_partial, gs_h, red_out;
@@ -249,6 +261,12 @@ void ilu_solve(tp_ctx *c, const double *r, double *x, const double *addto, int n
 void amg_build(tp_ctx *c, Amg *&amg, const GridDev &g0, const double strength[3]);
 void amg_setup(tp_ctx *c, Amg *amg, const Stencil &A0);
 void amg_vcycle(tp_ctx *c, Amg *amg, const double *b, double *x);
+// system AMG (2x2 blocks on (p,T))
+void bamg_build(tp_ctx *c, BAmg *&amg, const GridDev &g0, const double strength[3]);
+void bamg_setup(tp_ctx *c, BAmg *amg, const BStencil &A0);
+void bamg_vcycle(tp_ctx *c, BAmg *amg, const double *b, double *x);     // b, x: 2 planes, stride = ntot of the grid
+void bamg_destroy(BAmg *amg);
+int bamg_levels(const BAmg *amg);
 // comm
 void halo_exchange(tp_ctx *c, const GridDev &g, double *x, int nf, long fstride);
 void halo_exchange_raw(tp_ctx *c, const GridDev &g, void *x, int nf, size_t fstride_bytes, size_t elem_bytes);

@@ -59,9 +59,53 @@ static void face_strengths(tp_ctx *c, double st[3]) {
     for (int a = 0; a < 3; ++a) st[a] = acc[3 + a] > 0 ? acc[a] / acc[3 + a] : 0.0;
 }
 
+// the captured pc_apply graphs bake in buffer addresses and options: invalidate them when any changes
+static void refresh_pc_signature(tp_ctx *c) {
+    const uintptr_t sig[] = {(uintptr_t)c->opA00.base, (uintptr_t)c->opA01.base, (uintptr_t)c->opA10.base,
+                             (uintptr_t)c->Sm.p, (uintptr_t)c->ilu.fwd.p, (uintptr_t)c->amg_p, (uintptr_t)c->amg_T, (uintptr_t)c->bamg,
+                             (uintptr_t)c->w1.p, (uintptr_t)c->w3.p, (uintptr_t)c->w4.p, (uintptr_t)c->dcoef.p,
+                             (uintptr_t)c->opt.amg_nu, (uintptr_t)c->opt.pc_kind, (uintptr_t)c->opt.decoup,
+                             (uintptr_t)c->opt.amg_single, (uintptr_t)c->opt.amg_gather_cells, (uintptr_t)c->opt.schur_a11, (uintptr_t)c->opt.amg_full_levels, (uintptr_t)c->opt.amg_coarse_pre, (uintptr_t)c->opt.amg_coarse_post, (uintptr_t)c->opt.amg_tail_post, (uintptr_t)c->opt.amg_mid_skip,
+                             (uintptr_t)c->ilu.ntiles, (uintptr_t)c->ilu.nsteps};
+    uintptr_t h = 1469598103934665603ull;
+    for (uintptr_t v : sig) h = (h ^ v) * 1099511628211ull;
+    if (h != c->pc_sig) { c->pc_sig = h; c->graph_epoch++; }
+}
+
+// pc_cptramg[_QI|_TI] (twophase.py:552-566): CPTRStage1PC.update with ONE system-AMG V-cycle as stage-1 solver
+static void pc_setup_sysamg(tp_ctx *c) {
+    TP_REQUIRE(c->b == 3, "pc_cptramg is a two-phase preconditioner");
+    TP_REQUIRE(c->opt.decoup >= 0 && c->opt.decoup <= 2, "pc_cptramg: decoupling No, QI or TI");
+    decouple(c);
+    const GridDev gam = c->dist ? c->gfull : make_grid(c->g.n0, c->g.n1, c->g.n2, c->g.n2, 0);
+    if (!c->bamg) {
+        double st[3];
+        face_strengths(c, st);             // the pressure's coarsening schedule
+        bamg_build(c, c->bamg, gam, st);
+    }
+    const long nt = c->g.ntot;
+    BStencil A0;
+    if (c->opt.decoup == 0) { A0.base = c->J.p; A0.ss = (long)c->b * c->b * nt; A0.rs = (long)c->b * nt; A0.cs = nt; }
+    else { A0.base = c->At.p; A0.ss = 4 * nt; A0.rs = 2 * nt; A0.cs = nt; }
+    if (c->dist) {
+        // the hierarchy lives on the gathered global grid, replicated on every rank (as small scalar hierarchies do)
+        const size_t ng = (size_t)c->gfull.ntot;
+        if (c->gAt.n < 28 * ng) { c->gAt.alloc(28 * ng); c->gvec.alloc(4 * ng); }
+        for (int s = 0; s < 7; ++s)
+            for (int q = 0; q < 2; ++q)       // the two column planes of a block row are nt apart on both sides
+                gather_slabs(c, A0.at(s, q, 0), A0.cs, c->gAt.p + ((size_t)(s * 2 + q) * 2) * ng, (long)ng, 2);
+        A0.base = c->gAt.p; A0.ss = 4 * (long)ng; A0.rs = 2 * (long)ng; A0.cs = (long)ng;
+    }
+    bamg_setup(c, c->bamg, A0);
+    ilu_factor(c);
+    c->pc_ready = true;
+    refresh_pc_signature(c);
+}
+
 void pc_setup(tp_ctx *c) {
     TP_REQUIRE(c->jac_ready, "pc_setup needs an assembled Jacobian");
     ensure_work(c);
+    if (sysamg_of(c->opt)) { pc_setup_sysamg(c); return; }
     const bool cptr = schur_of(c->opt);       // fieldsplit-Schur stage on (p,T): pc_cptr and pc_fieldsplit_cd
     if (c->opt.pc_kind == 1) TP_REQUIRE(c->b == 3, "pc_cptr is a two-phase preconditioner");
     if (c->opt.pc_kind == 2) {
@@ -149,16 +193,7 @@ void pc_setup(tp_ctx *c) {
     // stage 2: numeric block-ILU(0) of every tile of this rank's slab
     if (c->dist) ilu_factor(c);
     c->pc_ready = true;
-    // the captured pc_apply graph bakes in buffer addresses and options: invalidate it when any changes
-    const uintptr_t sig[] = {(uintptr_t)c->opA00.base, (uintptr_t)c->opA01.base, (uintptr_t)c->opA10.base,
-                             (uintptr_t)c->Sm.p, (uintptr_t)c->ilu.fwd.p, (uintptr_t)c->amg_p, (uintptr_t)c->amg_T,
-                             (uintptr_t)c->w1.p, (uintptr_t)c->w3.p, (uintptr_t)c->w4.p, (uintptr_t)c->dcoef.p,
-                             (uintptr_t)c->opt.amg_nu, (uintptr_t)c->opt.pc_kind, (uintptr_t)c->opt.decoup,
-                             (uintptr_t)c->opt.amg_single, (uintptr_t)c->opt.amg_gather_cells, (uintptr_t)c->opt.schur_a11, (uintptr_t)c->opt.amg_full_levels, (uintptr_t)c->opt.amg_coarse_pre, (uintptr_t)c->opt.amg_coarse_post, (uintptr_t)c->opt.amg_tail_post, (uintptr_t)c->opt.amg_mid_skip,
-                             (uintptr_t)c->ilu.ntiles, (uintptr_t)c->ilu.nsteps};
-    uintptr_t h = 1469598103934665603ull;
-    for (uintptr_t v : sig) h = (h ^ v) * 1099511628211ull;
-    if (h != c->pc_sig) { c->pc_sig = h; c->graph_epoch++; }
+    refresh_pc_signature(c);
 }
 
 // y = B1 x :  CPRStage1PC.apply (preconditioners.py:881-903) / CPTRStage1PC.apply (:1550-1567)
@@ -179,6 +214,20 @@ void stage1_apply(tp_ctx *c, const double *x, double *y, bool zero_secondary) {
     } else {
         stage1_rhs(c, x, 0, r0);                   // r_p = x_p - (D_ps D_ss^-1) x_s
         if (npri == 2) stage1_rhs(c, x, 1, r1);
+    }
+    if (sysamg_of(c->opt)) {
+        // pc_cptramg: y_pT = K(Atilde_00) r_pT, one V-cycle of the 2x2-block system AMG (r0, r1 are adjacent planes)
+        if (c->dist) {
+            const long ng = c->gfull.ntot;
+            gather_slabs(c, r0, nt, c->gvec.p, ng, 2);
+            bamg_vcycle(c, c->bamg, c->gvec.p, c->gvec.p + 2 * ng);
+            const long off = g.np * c->grid.off2;          // my slab INCLUDING its halo planes
+            vec_copy(c, c->gvec.p + 2 * ng + off, y, nt);
+            vec_copy(c, c->gvec.p + 3 * ng + off, y + nt, nt);
+        } else {
+            bamg_vcycle(c, c->bamg, r0, y);
+        }
+        return;
     }
     if (c->dist && c->amg_p->dist_levels == 0) {
         // gathered global system: work vectors gr0, gr1, gy0, gy1, gt, gw on the global grid
@@ -226,7 +275,7 @@ static void pc_apply_body(tp_ctx *c, const double *x, double *y) {
     const int npri = npri_of(c->opt);
     // (y's secondary fields are left untouched: the second stage below never reads them and overwrites them)
     stage1_apply(c, x, y, false);                 // multi-GPU, replicated stage 1: y comes back with live halo planes
-    if (c->dist && c->amg_p->dist_levels > 0) halo_exchange(c, c->g, y, npri, c->g.ntot);
+    if (c->dist && c->amg_p && c->amg_p->dist_levels > 0) halo_exchange(c, c->g, y, npri, c->g.ntot);
     if (c->opt.pc_kind == 2) return;                          // pc_fieldsplit_cd: the Schur stage IS the preconditioner
     resid_block_cols(c, c->J.p, x, y, npri, c->w1.p);        // secondary fields of y are zero
     ilu_solve(c, c->w1.p, y, y, npri);                       // y = y + M^-1 r  (y's secondary fields are zero: not read)

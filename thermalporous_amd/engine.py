@@ -60,7 +60,7 @@ API_SYMBOLS = (
     "tp_set_field", "tp_finalize_fields", "tp_set_sources", "tp_set_state", "tp_get_state", "tp_set_old_state",
     "tp_set_dt", "tp_get_old_state", "tp_restore_state", "tp_saturation_range", "tp_clamp_saturation",
     "tp_residual", "tp_jacobian", "tp_get_residual", "tp_export_jacobian", "tp_export_schur",
-    "tp_well_rates", "tp_vec_create", "tp_vec_set", "tp_vec_get", "tp_vec_copy_residual", "tp_spmv", "tp_pc_setup",
+    "tp_well_rates", "tp_vec_create", "tp_vec_create_batch", "tp_vec_dot_batch", "tp_vec_axpy_batch", "tp_vec_norm2", "tp_vec_set", "tp_vec_get", "tp_vec_copy_residual", "tp_spmv", "tp_pc_setup",
     "tp_pc_apply", "tp_stage1_update", "tp_stage1_apply", "tp_ilu0_factor", "tp_ilu0_solve", "tp_amg_setup",
     "tp_amg_vcycle", "tp_schur_apply", "tp_fgmres", "tp_newton_solve", "tp_time_kernel", "tp_amg_info", "tp_amg_layout",
 )
@@ -120,7 +120,7 @@ def tiles_for_blocks(n, nblocks, max_cols=64):
     return best[1]
 
 
-_PC = {"cpr": 0, "cptr": 1, "fieldsplit_cd": 2}
+_PC = {"cpr": 0, "cptr": 1, "fieldsplit_cd": 2, "cptramg": 3}
 _DECOUP = {"No": 0, "QI": 1, "TI": 2, "QI_temp": 3, "TI_temp": 4}
 
 
@@ -355,6 +355,29 @@ class HipEngine:
         out = np.empty(self.b*self.ntot)
         self._ck(self.lib.tp_vec_get(self.ctx, self.vec(name), _dptr(out)))
         return self._strip_halo(out, self.b).copy()
+
+    def vec_batch(self, prefix, n):
+        """n vectors '<prefix>0'..'<prefix>{n-1}' in one allocation (a Krylov basis): VecMDot/VecMAXPY run in one pass."""
+        if prefix + "0" not in self._vec_ids:
+            i = C.c_int32()
+            self._ck(self.lib.tp_vec_create_batch(self.ctx, int(n), C.byref(i)))
+            for k in range(n):
+                self._vec_ids[prefix + str(k)] = i.value + k
+        return self._vec_ids[prefix + "0"]
+
+    def dot_batch(self, prefix, n, w):
+        out = np.zeros(n)
+        self._ck(self.lib.tp_vec_dot_batch(self.ctx, self.vec_batch(prefix, n), int(n), self.vec(w), _dptr(out)))
+        return out
+
+    def axpy_batch(self, prefix, n, coef, w):
+        coef = np.ascontiguousarray(coef, dtype=float)
+        self._ck(self.lib.tp_vec_axpy_batch(self.ctx, self.vec_batch(prefix, n), int(n), _dptr(coef), self.vec(w)))
+
+    def norm2(self, x):
+        out = C.c_double()
+        self._ck(self.lib.tp_vec_norm2(self.ctx, self.vec(x), C.byref(out)))
+        return out.value
 
     def spmv(self, x, y):
         self._ck(self.lib.tp_spmv(self.ctx, self.vec(x), self.vec(y)))

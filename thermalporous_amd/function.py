@@ -31,22 +31,41 @@ class _Dat():
     def __init__(self, owner):
         self._o = owner
 
+    def _grouped(self, d):
+        """The reference's mixed-space view: one array per sub-space.  With ``vector=True`` (twophase.py:19-21) that is
+        [pT of shape (ncell, 2), S_o]: the interleaved block is a COPY of the two field planes (read-only: the device
+        keeps field planes; S_o, the only entry the time loop writes, stays a live view)."""
+        out = []
+        for grp in self._o._groups:
+            if len(grp) == 1:
+                out.append(d[grp[0]])
+            else:
+                a = np.stack([d[i] for i in grp], axis=1)
+                a.setflags(write=False)
+                out.append(a)
+        return out
+
     @property
     def data(self):
         d = self._o._data                  # read-write access: device copy becomes stale
+        if self._o._groups is not None:
+            return self._grouped(d)
         return [d[i] for i in range(d.shape[0])]
 
     @property
     def data_ro(self):
         d = self._o._read()
+        if self._o._groups is not None:
+            return self._grouped(d)
         return [d[i] for i in range(d.shape[0])]
 
 
 class Function():
     """Mixed DQ0 function: ``nfields`` arrays of ncell doubles (field-major, like V*V*V)."""
 
-    def __init__(self, nfields, ncell, name="solution"):
+    def __init__(self, nfields, ncell, name="solution", groups=None):
         self._store = np.zeros((nfields, ncell))
+        self._groups = groups          # e.g. [(0, 1), (2,)] for VectorFunctionSpace(dim=2) x V; None: one array per field
         self.dat = _Dat(self)
         self._name = name
         self.host_stale = False         # device holds newer data than _store

@@ -95,8 +95,10 @@ class CPTRStage1PC(CPRStage1PC):
 
     def initialize(self, pc):
         appctx = self.get_appctx(pc)
-        if appctx.get("vector"):
-            raise NotImplementedError("vector=True (interleaved p,T; pc_cptramg*/pc_cptrlu*) is outside the hot path")
+        # the stage-1 solver is read from the options prefix <prefix>cpr_stage1_ (:1374): fieldsplit-Schur (pc_cptr) or
+        # one system-AMG V-cycle on the interleaved (p,T) operator (pc_cptramg*, which force vector=True :935-955)
+        if pc.engine.opts["pc"] == "cptramg" or (appctx.get("vector") and pc.engine.opts["pc"] != "cptr"):
+            self.kind = "cptramg"
         CPRStage1PC.initialize(self, pc)
 
 

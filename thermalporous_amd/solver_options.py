@@ -201,26 +201,41 @@ def engine_options(solver_parameters, model_name, decoup="No"):
     elif pytype.endswith("CPTRStage1PC"):
         if model_name != "Two-phase":
             raise NotImplementedError("CPTRStage1PC needs the two-phase model")
-        o["pc"] = "cptr"
-        if _take(sp, used, "sub_0_cpr_stage1_pc_type", ("fieldsplit",)) is None:
-            raise NotImplementedError("CPTRStage1PC is implemented with the fieldsplit-Schur stage-1 solver of "
-                                      "pc_cptr; system-AMG/LU variants (pc_cptramg*, pc_cptrlu*) are not")
-        _take(sp, used, "sub_0_cpr_stage1_pc_fieldsplit_type", ("schur",))
-        fact = str(_take(sp, used, "sub_0_cpr_stage1_pc_fieldsplit_schur_fact_type", None, "")).upper()
-        if "sub_0_cpr_stage1_pc_fieldsplit_type" not in used or fact != "FULL":
-            raise NotImplementedError("CPTR stage 1: fieldsplit schur FULL only (twophase.py:536-538)")
-        pre = _take(sp, used, "sub_0_cpr_stage1_pc_fieldsplit_schur_precondition", ("a11",))
-        o["schur_a11"] = pre == "a11"                   # pc_cptr_a11 (twophase.py:598-616)
-        _take_vcycle(sp, "sub_0_cpr_stage1_fieldsplit_0_", used)
-        if pre == "a11":
-            _take_vcycle(sp, "sub_0_cpr_stage1_fieldsplit_1_", used)
+        kind = _take(sp, used, "sub_0_cpr_stage1_pc_type", ("fieldsplit", "hypre"))
+        if kind is None:
+            raise NotImplementedError("CPTRStage1PC needs sub_0_cpr_stage1_pc_type fieldsplit (pc_cptr) or hypre "
+                                      "(pc_cptramg*); the LU variants (pc_cptrlu*) are not on the hot path")
+        if kind == "hypre":
+            # pc_cptramg[_QI|_TI] (twophase.py:552-566): ONE BoomerAMG V-cycle on the interleaved (p,T) system
+            o["pc"] = "cptramg"
+            _take(sp, used, "sub_0_cpr_stage1_pc_hypre_type", ("boomeramg",))
+            _take(sp, used, "sub_0_cpr_stage1_pc_hypre_boomeramg_max_iter", (1,))
+            _take(sp, used, "sub_0_cpr_stage1_ksp_type", ("preonly",))
+            if "sub_0_cpr_stage1_pc_hypre_type" not in used:
+                raise NotImplementedError("sub_0_cpr_stage1_pc_hypre_type boomeramg expected")
+            for k in sp:
+                if k.startswith("sub_0_cpr_stage1_pc_hypre_") and k not in used:
+                    raise NotImplementedError("%s: hypre tuning options do not apply to this build's own AMG" % k)
+            if o["decoup"] not in ("No", "QI", "TI"):
+                raise NotImplementedError("pc_cptramg: decoupling No, QI or TI (twophase.py:552-566)")
         else:
-            _take(sp, used, "sub_0_cpr_stage1_fieldsplit_1_ksp_type", ("preonly",))
-            _take(sp, used, "sub_0_cpr_stage1_fieldsplit_1_pc_type", ("python",))
-            py = str(_take(sp, used, "sub_0_cpr_stage1_fieldsplit_1_pc_python_type", None, ""))
-            if not py.endswith("ConvDiffSchurTwoPhasesPC"):
-                raise NotImplementedError("CPTR stage 1: the Schur split must be ConvDiffSchurTwoPhasesPC or a11")
-            _take_vcycle(sp, "sub_0_cpr_stage1_fieldsplit_1_schur_", used)
+            o["pc"] = "cptr"
+            _take(sp, used, "sub_0_cpr_stage1_pc_fieldsplit_type", ("schur",))
+            fact = str(_take(sp, used, "sub_0_cpr_stage1_pc_fieldsplit_schur_fact_type", None, "")).upper()
+            if "sub_0_cpr_stage1_pc_fieldsplit_type" not in used or fact != "FULL":
+                raise NotImplementedError("CPTR stage 1: fieldsplit schur FULL only (twophase.py:536-538)")
+            pre = _take(sp, used, "sub_0_cpr_stage1_pc_fieldsplit_schur_precondition", ("a11",))
+            o["schur_a11"] = pre == "a11"                   # pc_cptr_a11 (twophase.py:598-616)
+            _take_vcycle(sp, "sub_0_cpr_stage1_fieldsplit_0_", used)
+            if pre == "a11":
+                _take_vcycle(sp, "sub_0_cpr_stage1_fieldsplit_1_", used)
+            else:
+                _take(sp, used, "sub_0_cpr_stage1_fieldsplit_1_ksp_type", ("preonly",))
+                _take(sp, used, "sub_0_cpr_stage1_fieldsplit_1_pc_type", ("python",))
+                py = str(_take(sp, used, "sub_0_cpr_stage1_fieldsplit_1_pc_python_type", None, ""))
+                if not py.endswith("ConvDiffSchurTwoPhasesPC"):
+                    raise NotImplementedError("CPTR stage 1: the Schur split must be ConvDiffSchurTwoPhasesPC or a11")
+                _take_vcycle(sp, "sub_0_cpr_stage1_fieldsplit_1_schur_", used)
     else:
         raise NotImplementedError("sub_0_pc_python_type %r" % pytype)
     if o["decoup"] not in ("No", "QI", "TI", "QI_temp", "TI_temp"):

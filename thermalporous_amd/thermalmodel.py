@@ -92,8 +92,9 @@ class ThermalModel:
         self.spec = build_spec(self.geo, self.case, self.params, nphase)
         self.ncell = self.geo.Nx*self.geo.Ny*self.geo.Nz
         self.nfields = nphase + 1
-        self.u = Function(self.nfields, self.ncell)
-        self.u_ = Function(self.nfields, self.ncell)
+        groups = [(0, 1), (2,)] if getattr(self, "vector", False) and nphase == 2 else None
+        self.u = Function(self.nfields, self.ncell, groups=groups)
+        self.u_ = Function(self.nfields, self.ncell, groups=groups)
         self.F = "DG0/TPFA residual assembled on the device (csrc/tp_assembly.hip)"
 
     def init_solver(self):
@@ -289,7 +290,8 @@ class ThermalModel:
         """pressure / temperature / saturation_o .pvd collections next to the results file (:113-133, :303-322).
         Reading the state is a collective on several ranks (slabs are gathered); rank 0 writes."""
         from .output import File
-        fields = [self.u.dat.data_ro[f] for f in range(self.nfields)]
+        d = self.u._read()
+        fields = [d[f] for f in range(self.nfields)]
         if self.comm.rank != 0:
             return
         if self._outfiles is None:

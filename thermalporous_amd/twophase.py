@@ -25,10 +25,14 @@ class TwoPhase(ThermalModel):
         self.solver_parameters = solver_parameters
         self.init_solver_parameters()
         if self.vector:
-            raise NotImplementedError("vector=True (interleaved p,T space for pc_cptramg*/pc_cptrlu*) is outside "
-                                      "the hot path")
-        self.W = ("DQ0", "DQ0", "DQ0")
-        self.i_S_o = 2
+            # VectorFunctionSpace(dim=2) x V (:19-21): in the reference this interleaves (p,T) in memory so that hypre sees
+            # 2x2 blocks (pc_cptramg*).  Here it is a LAYOUT FLAG: the device keeps field planes (the system AMG reads the
+            # (p,T) blocks from them); only the host view follows the reference: u.dat.data = [pT (n x 2), S_o]
+            self.W = ("VectorDQ0(dim=2)", "DQ0")
+            self.i_S_o = 1
+        else:
+            self.W = ("DQ0", "DQ0", "DQ0")
+            self.i_S_o = 2
         self.save = save
         self.n_save = n_save
         self.small_dt_start = small_dt_start
@@ -120,6 +124,16 @@ class TwoPhase(ThermalModel):
                          "sub_1_sub_pc_type": "ilu",
                          "sub_1_sub_pc_factor_levels": 0,
                          "mat_type": "aij"}
+        pc_cptramg = {"pc_type": "composite",     # (:552-563) system AMG on the interleaved (p,T) operator
+                      "pc_composite_type": "multiplicative",
+                      "pc_composite_pcs": "python,bjacobi",
+                      "sub_0_pc_python_type": "thermalporous.preconditioners.CPTRStage1PC",
+                      "sub_0_cpr_stage1_pc_type": "hypre",
+                      "sub_0_cpr_stage1_pc_hypre_type": "boomeramg",
+                      "sub_0_cpr_stage1_pc_hypre_boomeramg_max_iter": 1,
+                      "sub_1_sub_pc_type": "ilu",
+                      "sub_1_sub_pc_factor_levels": 0,
+                      "mat_type": "aij"}
         pc_cptr_a11 = {k: v for k, v in pc_cptr.items() if not k.startswith("sub_0_cpr_stage1_fieldsplit_1")}   # (:598-616)
         pc_cptr_a11.update({"sub_0_cpr_stage1_pc_fieldsplit_schur_precondition": "a11",
                             "sub_0_cpr_stage1_fieldsplit_1": v_cycle, "sub_1_pc_bjacobi_blocks": 1})
@@ -128,7 +142,10 @@ class TwoPhase(ThermalModel):
                    "pc_cpr_TI": {**pc_cpr, "sub_0_cpr_decoup": "TI"},      # (:595)
                    "pc_cpr_QI_temp": {**pc_cpr, "sub_0_cpr_decoup": "QI_temp"},      # (:596)
                    "pc_cpr_TI_temp": {**pc_cpr, "sub_0_cpr_decoup": "TI_temp"},      # (:597)
-                   "pc_cpr_gmres": pc_cpr_gmres, "pc_cptr_gmres": pc_cptr_gmres}
+                   "pc_cpr_gmres": pc_cpr_gmres, "pc_cptr_gmres": pc_cptr_gmres,
+                   "pc_cptramg": pc_cptramg,                                           # (:552-563)
+                   "pc_cptramg_QI": {**pc_cptramg, "sub_0_cpr_decoup": "QI"},        # (:565)
+                   "pc_cptramg_TI": {**pc_cptramg, "sub_0_cpr_decoup": "TI"}}        # (:566)
         parameters = newton_krylov
         if self.solver_parameters is None:
             self.solver_parameters = "pc_cptr_gmres"       # the reference's default (:930); same algebra as pc_cptr
@@ -136,6 +153,8 @@ class TwoPhase(ThermalModel):
             if self.solver_parameters not in presets:
                 raise NotImplementedError("two-phase preset %r is outside the hot path; available: %s"
                                           % (self.solver_parameters, sorted(presets)))
+            if self.solver_parameters.startswith("pc_cptramg"):
+                self.vector = True                           # forced by the reference (:935-943)
             parameters.update(presets[self.solver_parameters])
             self.solver_parameters = parameters
         if "sub_0_cpr_decoup" in self.solver_parameters:      # (:999-1002)
