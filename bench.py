@@ -50,7 +50,7 @@ CONFIGS = {
     "c3": ("BASELINE config 3: two-phase 2D SPE10-like 60x220 layer, Peaceman wells, pc_cptr, maxdt 1 day", (60, 220, 1)),
     "c4": ("BASELINE config 4: two-phase 3D SPE10-like 60x220x85, wells+heaters, pc_cptr, maxdt 0.1 day", (60, 220, 85)),
     "c5slab": ("BASELINE config 5, ONE of its 8 slabs: two-phase 3D 240x110x340 (60x220x85 field upsampled x4), "
-               "21+21 'large' wells, pc_cptr, maxdt 0.1 day", (240, 110, 340)),
+               "21+21 constant-rate 'large' wells (1e-7 m^3/s), pc_cptr, maxdt 0.1 day", (240, 110, 340)),
 }
 
 
@@ -99,14 +99,41 @@ def build_case(name, Nxyz=None):
         case = WellHeaterCase(params, geo, prod_points=prod, inj_points=inj)
     elif name == "c5slab":
         geo = SPE10Model3D(Nx, Ny, Nz, params, refine=4)      # cells 1/4 of the SPE10 size in every direction
-        # the 'large' pattern (wellcase.py:58-64): 21 + 21 wells.  Their rate is scaled with the cell volume (1/64 of an
-        # SPE10 cell): 2e-4 m^3/s into a 0.17 m^3 cell makes even dt = 0.5 s diverge within a few steps (GPU and CPU
-        # oracle alike); rate/64 is the same forcing per pore volume as on config 4
-        params.rate = 2e-4/64
-        case = WellHeaterCase(params, geo, well_case="large")
+        # 21 + 21 wells on the 'large' pattern (wellcase.py:58-64) driven as the reference's own 3-D runs drive them:
+        # constant rate 1e-7 m^3/s (tests_twophase/test3D_homo_wells.py:11,90).  Peaceman wells at config 4's 2e-4 m^3/s
+        # are not usable on cells of 0.17 m^3: Newton stalls in a limit cycle of the rate-cap branch at any dt
+        params.rate = 1e-7
+        from thermalporous_amd.wellcase import WellCase
+        prod, inj = WellCase(params, geo, well_case=None).named_points("large")
+        # The reference runs this pattern on homogeneous fields, where every cell is live.  On the SPE10-like field 2.5 %
+        # of the cells have zero porosity and the permeability spans 8 decades: a constant-rate well in a dead cell has
+        # no physical solution path (measured: the time loop collapses dt to 6e-3 s).  Each well is therefore completed
+        # in the most permeable porous cell of its 3x3x3 neighbourhood, as a reservoir engineer would.
+        prod, inj = ([_live_cell_centre(geo, w) for w in pts] for pts in (prod, inj))
+        case = WellCase(params, geo, prod_points=prod, inj_points=inj, constant_rate=True)
     else:
         raise ValueError(name)
     return params, geo, case, TwoPhase, dict(maxdt=0.1, small_dt_start=True, solver_parameters="pc_cptr")
+
+
+def _live_cell_centre(geo, w):
+    """Centre of the cell with the largest phi*K_x among the 27 cells around the point w = [x, y, z]."""
+    D = (geo.Dx, geo.Dy, geo.Dz)
+    N = (geo.Nx, geo.Ny, geo.Nz)
+    i0 = [min(max(int(w[a]/D[a]), 0), N[a] - 1) for a in range(3)]
+    best, arg = -1.0, i0
+    for di in (-1, 0, 1):
+        for dj in (-1, 0, 1):
+            for dk in (-1, 0, 1):
+                i, j, k = i0[0] + di, i0[1] + dj, i0[2] + dk
+                if not (0 <= i < N[0] and 0 <= j < N[1] and 0 <= k < N[2]):
+                    continue
+                v = float(geo.phi[i, j, k]*geo.K_x[i, j, k])
+                if v > best:
+                    best, arg = v, (i, j, k)
+    # 0.2 m off the centre in x: a point within the well radius (0.1 m) of a cell centre would spread the delta over every
+    # layer within 1 m of it (wellcase.py:141-155), dead cells included; off-centre, the nearest-centre rule picks this cell
+    return [(arg[0] + 0.5)*D[0] + 0.2, (arg[1] + 0.5)*D[1], (arg[2] + 0.5)*D[2]]
 
 
 def make_model(name, engine_factory=None, Nxyz=None, **over):

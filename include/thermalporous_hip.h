@@ -158,6 +158,14 @@ int tp_vec_copy_residual(tp_ctx *ctx, int32_t id);        /* vec <- R */
 
 /* operators (PETSc MatMult AIJ / PCApply in the reference: option dicts singlephase.py:303-354,
  * twophase.py:478-482,531-597) */
+/* KSPMonitorSet analogue for the reference's per-field residual monitor (option key ksp_monitor_residuals,
+ * thermalmodel.py:44-74: ksp.buildResidual() split by field).  When set, every FGMRES iteration builds the current
+ * iterate x_j = Z y_j, the true residual b - J x_j (one extra SpMV) and its 2-norm per field, and calls
+ * cb(its, recurrence_rnorm, field_norms[nfields], user).  Debug aid: costs about one Krylov iteration per call.
+ * NULL removes the monitor. */
+typedef void (*tp_ksp_monitor_fn)(int32_t its, double rnorm, const double *field_norms, int32_t nfields, void *user);
+int tp_set_ksp_monitor(tp_ctx *ctx, tp_ksp_monitor_fn cb, void *user);
+
 /* PETSc Vec kernels of one Krylov iteration (SURVEY.md 8b minimum list; KSP fgmres, twophase.py:426-432):
  *   tp_vec_create_batch  n vectors in ONE allocation (ids first..first+n-1): a Krylov basis
  *   tp_vec_dot_batch     out[i] = <v_{first+i}, w>, i < n   (VecMDot: one pass over w, one host sync)

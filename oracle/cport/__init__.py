@@ -64,15 +64,23 @@ def _d(a):
     return a.ctypes.data_as(C.POINTER(C.c_double))
 
 
+def _usable_cpus():
+    try:
+        return len(os.sched_getaffinity(0))
+    except AttributeError:
+        return os.cpu_count() or 1
+
+
+# measured at import time: once libgomp is loaded with OMP_PROC_BIND=true the calling thread is pinned to ONE core and
+# sched_getaffinity would report 1
+_NCPU = _usable_cpus()
+
+
 def default_threads():
     """Threads for the OpenMP loops: the CPUs this process may run on, at most 16 (the CPU share of a one-GPU box:
     os.cpu_count() there reports the whole host, and 100+ pinned threads on a 16-CPU quota crawl); TP_CPU_THREADS
     overrides."""
-    try:
-        n = len(os.sched_getaffinity(0))
-    except AttributeError:
-        n = os.cpu_count() or 1
-    return int(os.environ.get("TP_CPU_THREADS", min(n, 16)))
+    return int(os.environ.get("TP_CPU_THREADS", min(_NCPU, 16)))
 
 
 class CPortEngine:

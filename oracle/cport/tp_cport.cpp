@@ -23,6 +23,7 @@
 #include <cstdint>
 #include <cstdio>
 #include <cstring>
+#include <cstdlib>
 #include <string>
 #include <vector>
 
@@ -391,6 +392,11 @@ struct SemiAMG {
             pre = coarse_pre;
             post = N <= 1024 ? tail_post : coarse_post;
             if (mid_skip && N > 1024 && ((l - full_levels) % 2 == 1)) { pre = 0; post = 0; }
+        }
+        if (l == 0) {      // experiment hook (cycle-shape studies only; unset in every test and in bench.py)
+            static const char *e0 = getenv("CP_L0_PRE"), *e1 = getenv("CP_L0_POST");
+            if (e0) pre = atoi(e0);
+            if (e1) post = atoi(e1);
         }
         double *r = wr[l].data(), *t = wt[l].data(), *x2 = wx[l].data();
         const double *rr;

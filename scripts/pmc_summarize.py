@@ -1,9 +1,9 @@
-"""Builds profiles/r01_pmc_traffic.json from two rocprofv3 PMC passes over scripts/pmc_probe.py:
+"""Builds profiles/r02_pmc_traffic.json from two rocprofv3 PMC passes over scripts/pmc_probe.py:
 
   cd /tmp && export TMPDIR=/tmp && cd $REPO
   TP_GRAPH=0 rocprofv3 --kernel-trace --pmc FETCH_SIZE --output-format csv -d gpurun_out/pmc_fetch -- python3 scripts/pmc_probe.py
   TP_GRAPH=0 rocprofv3 --kernel-trace --pmc WRITE_SIZE --output-format csv -d gpurun_out/pmc_write -- python3 scripts/pmc_probe.py
-  python3 scripts/pmc_summarize.py gpurun_out/pmc_fetch gpurun_out/pmc_write profiles/r01_pmc_traffic.json
+  python3 scripts/pmc_summarize.py gpurun_out/pmc_fetch gpurun_out/pmc_write profiles/r02_pmc_traffic.json
 
 (separate passes, no other trace domain; TP_GRAPH=0 because --pmc crashes on hipGraph replay).  Counters are in KiB;
 on gfx950 FETCH_SIZE reports half of the bytes of coalesced streaming reads (MI355X_MICROARCH.md, HBM section), so

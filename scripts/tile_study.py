@@ -3,7 +3,8 @@ sub_1_pc_bjacobi_blocks 1 / singlephase.py:348-349), on full-size C4 in the 0.1-
 
 Runs on the CPU with oracle/cport (the GPU engine cannot sweep a whole-slab tile with one wavefront) from the state
 bench.py saved at the start of its timed region:   python bench.py --no-cpu-baseline --save-state gpurun_out/c4_state.npz
-Usage: python scripts/tile_study.py gpurun_out/c4_state.npz [tile ...]      tile = t0,t1,t2
+Usage: python scripts/tile_study.py gpurun_out/c4_state.npz [dt=SECONDS] [tile ...]      tile = t0,t1,t2
+(dt: override the saved time step -- the saved dt = maxdt step may be one the time loop had to halve)
 """
 import json
 import os
@@ -18,7 +19,10 @@ from oracle import cport                         # noqa: E402
 
 st = np.load(sys.argv[1])
 u, dt = st["u"], float(st["dt"])
-tiles = [tuple(int(v) for v in a.split(",")) for a in sys.argv[2:]] or [(1 << 30, 8, 8), (1 << 30, 16, 16), (1 << 30, 1 << 30, 1 << 30)]
+args = sys.argv[2:]
+if args and args[0].startswith("dt="):
+    dt = float(args.pop(0)[3:])
+tiles = [tuple(int(v) for v in a.split(",")) for a in args] or [(1 << 30, 8, 8), (1 << 30, 16, 16), (1 << 30, 1 << 30, 1 << 30)]
 out = []
 for tile in tiles:
     # same options as the bench run, only the bjacobi tile differs

@@ -125,10 +125,12 @@ def test_linear_stages_parity(name, builder, kw, opts):
     if opts["pc"] == "cptramg":
         h.amg_vcycle(2, "x", 0, "y", 0)          # the system V-cycle on fields (p,T)
         assert rel2(h.vec_get("y")[:2], o.pc.amg_pT.vcycle(x[:2])) < 1e-10
+        # TI: the column sums cancel to ~1e-9 of their terms, so the summation order shows in d = D_0s/D_ss
+        stol = 1e-7 if opts.get("decoup") == "TI" else 1e-10
         h.stage1_apply("x", "y")
-        assert rel2(h.vec_get("y"), o.pc.stage1(x)) < 1e-10
+        assert rel2(h.vec_get("y"), o.pc.stage1(x)) < stol
         h.pc_apply("x", "y")
-        assert rel2(h.vec_get("y"), o.pc.apply(x)) < 1e-10
+        assert rel2(h.vec_get("y"), o.pc.apply(x)) < stol
         F = o.residual()
         h.residual()
         h.copy_residual_to("b")
@@ -218,4 +220,34 @@ def test_exported_vector_ops():
     with pytest.raises(Exception):
         h.vec("solo")
         h._ck(h.lib.tp_vec_dot_batch(h.ctx, h.vec("solo"), 2, h.vec("w"), None))
+    h.close()
+
+
+def test_ksp_residual_monitor_per_field():
+    """tp_set_ksp_monitor (the reference's ksp_monitor_residuals, thermalmodel.py:44-74): per-field norms of the TRUE
+    residual b - J x_j at every FGMRES iteration; they follow the recurrence norm and end at ||b - J d||."""
+    from thermalporous_amd.engine import HipEngine
+    spec, u0, *_ = cases.c4_spe10_3d(Nx=9, Ny=14, Nz=8, nphase=2)
+    h = HipEngine(spec, dict(pc="cptr", ksp_rtol=1e-8))
+    u = cases.perturbed_state(spec, seed=5, amp=0.3)
+    h.set_old(u0)
+    h.set_dt(8640.0)
+    h.set_state(u)
+    h.jacobian()
+    h.residual()
+    h.copy_residual_to("b")
+    seen = []
+    h.set_ksp_monitor(lambda its, rn, fn: seen.append((its, rn, list(fn))))
+    its, reason, rnorm = h.fgmres("b", "d")
+    h.set_ksp_monitor(None)
+    assert reason == 2 and len(seen) == its and [s[0] for s in seen] == list(range(1, its + 1))
+    for it, rn, fn in seen:
+        assert len(fn) == 3 and abs(np.sqrt(sum(v*v for v in fn)) - rn) <= 1e-6*seen[0][1] + 1e-3*rn
+    h.spmv("d", "Jd")
+    r = h.vec_get("b") - h.vec_get("Jd")
+    for f in range(3):
+        assert abs(np.linalg.norm(r[f]) - seen[-1][2][f]) <= 1e-9*np.linalg.norm(h.vec_get("b"))
+    n0 = len(seen)
+    h.fgmres("b", "d")                      # monitor removed: no more calls
+    assert len(seen) == n0
     h.close()

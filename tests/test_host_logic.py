@@ -111,6 +111,15 @@ def test_spe10_slice_maker_layout(tmp_path):
     assert s[i, j, 5 - 1 - kk] == phi[(i + 1) + (j + 2)*60 + (kk + 3)*220*60]
     ky = np.load(tmp_path/"slice_perm_y.npy")
     assert np.isclose(ky[i, j, 5 - 1 - kk], 2*phi[(i + 1) + (j + 2)*60 + (kk + 3)*220*60]*9.869233e-10)
+    # vertical sections (create_SPE10_slicexz.py:9-99): no z flip there; perm_y is Kz
+    mk.create_SPE10_slicexz(4, 6, x_shift=2, y_shift=5, z_shift=1, dirname=str(tmp_path))
+    s = np.load(tmp_path/"slice_phi.npy")
+    assert s.shape == (4, 6) and s[3, 2] == phi[(3 + 2) + 5*60 + (2 + 1)*220*60]
+    assert np.isclose(np.load(tmp_path/"slice_perm_y.npy")[3, 2], 3*phi[(3 + 2) + 5*60 + (2 + 1)*220*60]*9.869233e-10)
+    mk.create_SPE10_sliceyz(5, 3, x_shift=7, y_shift=2, z_shift=4, dirname=str(tmp_path))
+    s = np.load(tmp_path/"slice_phi.npy")
+    assert s.shape == (5, 3) and s[4, 1] == phi[7 + (4 + 2)*60 + (1 + 4)*220*60]
+    assert np.isclose(np.load(tmp_path/"slice_perm_x.npy")[4, 1], 2*phi[7 + (4 + 2)*60 + (1 + 4)*220*60]*9.869233e-10)
 
 
 def test_solver_option_mapping_and_rejections():

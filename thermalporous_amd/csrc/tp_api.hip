@@ -560,6 +560,14 @@ int tp_vec_create(tp_ctx *c, int32_t *id) {
     TP_API_END
 }
 
+int tp_set_ksp_monitor(tp_ctx *c, tp_ksp_monitor_fn cb, void *user) {
+    TP_API_BEGIN
+    TP_REQUIRE(c, "null argument");
+    c->monitor = cb;
+    c->monitor_user = user;
+    TP_API_END
+}
+
 int tp_vec_create_batch(tp_ctx *c, int32_t n, int32_t *first_id) {
     TP_API_BEGIN
     TP_REQUIRE(c && n >= 1 && first_id, "bad arguments");

@@ -222,6 +222,8 @@ struct tp_ctx {
     tp::GridDev gfull;
     tp::DBuf<double> gA00, gA01, gA10, gSm, gvec;   // operators: 7 planes each; gvec: work vectors
     long vcycles = 0;
+    tp_ksp_monitor_fn monitor = nullptr;      // per-field true-residual monitor (ksp_monitor_residuals)
+    void *monitor_user = nullptr;
     ~tp_ctx();
 };
 
@@ -242,6 +244,7 @@ void multi_dot(tp_ctx *c, int nf, const double *V, long vstride, int k, const do
 void multi_axpy(tp_ctx *c, int nf, const double *V, long vstride, int k, const double *hcoef_host, double sign,
                 double *w);          // w += sign * sum_i h_i V_i
 double norm2(tp_ctx *c, int nf, const double *x);
+void multi_norm2sq(tp_ctx *c, int nf, int nvec, const double *const *x, double *host_out);   // host_out[i] = <x_i, x_i>
 // h = V^T w ; w -= V h ; host_out[0..k-1] = h, host_out[k] = ||w||^2  (one host sync)
 void orthogonalize(tp_ctx *c, int nf, const double *V, long vstride, int k, double *w, double *host_out);
 void field_minmax(tp_ctx *c, const double *x, double *lo, double *hi);

@@ -52,9 +52,17 @@ __device__ __forceinline__ double wave_sum(double v) {
     return v;
 }
 
-__global__ __launch_bounds__(256) void k_multi_dot(GridDev g, int nf, const double *V, long vstride, int k,
-                                                   const double *w, const double *w2, double *partial,
-                                                   long nwaves) {
+// Memory-level parallelism: the Gram-Schmidt kernels stream k basis vectors past a register-resident piece of w.
+// Written one vector at a time (4 loads, then a 6-step cross-lane reduction, then the next vector) a wave keeps only
+// 2 KB in flight and the pass ran at 2.5 TB/s (rocprofv3, round 2: 119 us at k ~ 11).  MD_U vectors are now handled
+// together: MD_U*MD_CHUNK independent, unconditional loads per lane are issued before anything waits on them (tail
+// lanes read a valid address and multiply by w = 0) and the MD_U reductions interleave.  Summation order per output is
+// unchanged (bitwise identical results).
+constexpr int MD_U = 4;
+
+__global__ __launch_bounds__(256) void k_multi_dot(GridDev g, int nf, const double *__restrict__ V, long vstride, int k,
+                                                   const double *__restrict__ w, const double *__restrict__ w2,
+                                                   double *__restrict__ partial, long nwaves) {
     const long wave = ((long)blockIdx.x * blockDim.x + threadIdx.x) >> 6;
     const int lane = threadIdx.x & 63;
     if (wave >= nwaves) return;
@@ -68,14 +76,35 @@ __global__ __launch_bounds__(256) void k_multi_dot(GridDev g, int nf, const doub
         ok[j] = t < nall;
         const long tt = ok[j] ? t : 0;
         const long f = tt / g.nown, i = tt - f * g.nown;
-        idx[j] = f * g.ntot + g.np + i;
+        idx[j] = f * g.ntot + g.np + i;              // (tail lanes: entry 0 -- a valid address, weight 0)
         wv[j] = ok[j] ? w[idx[j]] : 0.0;
     }
-    for (int i = 0; i < k; ++i) {
+    int i = 0;
+    for (; i + MD_U <= k; i += MD_U) {
+        double v[MD_U][MD_CHUNK];
+#pragma unroll
+        for (int u = 0; u < MD_U; ++u)
+#pragma unroll
+            for (int j = 0; j < MD_CHUNK; ++j) v[u][j] = V[(long)(i + u) * vstride + idx[j]];
+        double s[MD_U];
+#pragma unroll
+        for (int u = 0; u < MD_U; ++u) {
+            s[u] = 0.0;
+#pragma unroll
+            for (int j = 0; j < MD_CHUNK; ++j) s[u] += v[u][j] * wv[j];
+        }
+#pragma unroll
+        for (int u = 0; u < MD_U; ++u) s[u] = wave_sum(s[u]);
+        if (lane == 0) {
+#pragma unroll
+            for (int u = 0; u < MD_U; ++u) partial[(long)(i + u) * nwaves + wave] = s[u];
+        }
+    }
+    for (; i < k; ++i) {
         const double *Vi = V + (long)i * vstride;
         double s = 0.0;
 #pragma unroll
-        for (int j = 0; j < MD_CHUNK; ++j) s += ok[j] ? Vi[idx[j]] * wv[j] : 0.0;
+        for (int j = 0; j < MD_CHUNK; ++j) s += Vi[idx[j]] * wv[j];
         s = wave_sum(s);
         if (lane == 0) partial[(long)i * nwaves + wave] = s;
     }
@@ -134,6 +163,22 @@ void multi_dot(tp_ctx *c, int nf, const double *V, long vstride, int k, const do
     TP_HIP(hipStreamSynchronize(c->stream));
 }
 
+// ||x_i||^2 of several vectors with ONE reduction launch, ONE all-reduce and ONE host sync (the three norms of SNES's
+// convergence test: ||F||, ||dx||, ||u||; each used to cost its own sync and -- on several GPUs -- its own all-reduce)
+void multi_norm2sq(tp_ctx *c, int nf, int nvec, const double *const *x, double *host_out) {
+    const long nw = md_nwaves(c, nf);
+    if ((long)c->gs_partial.n < (long)nvec * nw) c->gs_partial.alloc((size_t)(nvec + 32) * nw);
+    if ((long)c->red_out.n < nvec) c->red_out.alloc(nvec + 64);
+    for (int i = 0; i < nvec; ++i)
+        hipLaunchKernelGGL(k_multi_dot, grid_for(nw * 64), dim3(256), 0, c->stream, c->g, nf, x[i], 0L, 0, x[i], x[i],
+                           c->gs_partial.p + (long)i * nw, nw);
+    hipLaunchKernelGGL(k_reduce_partials, dim3(nvec), dim3(1024), 0, c->stream, c->gs_partial.p, nw, c->red_out.p);
+    TP_HIP(hipGetLastError());
+    allreduce_sum(c, c->red_out.p, nvec);
+    TP_HIP(hipMemcpyAsync(host_out, c->red_out.p, sizeof(double) * nvec, hipMemcpyDeviceToHost, c->stream));
+    TP_HIP(hipStreamSynchronize(c->stream));
+}
+
 double norm2(tp_ctx *c, int nf, const double *x) {
     double s = 0.0;
     multi_dot(c, nf, x, 0, 0, x, x, &s);
@@ -141,14 +186,22 @@ double norm2(tp_ctx *c, int nf, const double *x) {
 }
 
 // w += sign * sum_i h_i V_i  (VecMAXPY): one pass over w, k coalesced streams
-__global__ __launch_bounds__(256) void k_multi_axpy(GridDev g, int nf, const double *V, long vstride, int k,
-                                                    const double *h, double sign, double *w) {
+__global__ __launch_bounds__(256) void k_multi_axpy(GridDev g, int nf, const double *__restrict__ V, long vstride, int k,
+                                                    const double *__restrict__ h, double sign, double *w) {
     const long t = (long)blockIdx.x * blockDim.x + threadIdx.x;
     if (t >= g.nown * nf) return;
     const long f = t / g.nown, i = t - f * g.nown;
     const long c = f * g.ntot + g.np + i;
     double s = 0.0;
-    for (int j = 0; j < k; ++j) s += h[j] * V[(long)j * vstride + c];
+    int j = 0;
+    for (; j + MD_U <= k; j += MD_U) {          // MD_U independent loads in flight; same summation order
+        double v[MD_U];
+#pragma unroll
+        for (int u = 0; u < MD_U; ++u) v[u] = V[(long)(j + u) * vstride + c];
+#pragma unroll
+        for (int u = 0; u < MD_U; ++u) s += h[j + u] * v[u];
+    }
+    for (; j < k; ++j) s += h[j] * V[(long)j * vstride + c];
     w[c] += sign * s;
 }
 
@@ -167,23 +220,53 @@ void multi_axpy(tp_ctx *c, int nf, const double *V, long vstride, int k, const d
 // ---- one Gram-Schmidt step with a single host sync -------------------------------------------------
 // h = V^T w (k dots) ; w -= V h ; ||w||^2 -- the coefficients never leave the device between the dot and
 // the update, so an FGMRES iteration pays one D2H copy + sync here instead of three.
-__global__ __launch_bounds__(256) void k_multi_axpy_norm(GridDev g, int nf, const double *V, long vstride, int k,
-                                                         const double *h, double *w, double *partial, long nwaves) {
+__global__ __launch_bounds__(256) void k_multi_axpy_norm(GridDev g, int nf, const double *__restrict__ V, long vstride,
+                                                         int k, const double *__restrict__ h, double *w,
+                                                         double *__restrict__ partial, long nwaves) {
     const long wave = ((long)blockIdx.x * blockDim.x + threadIdx.x) >> 6;
     const int lane = threadIdx.x & 63;
     if (wave >= nwaves) return;
     const long nall = g.nown * nf;
-    double acc = 0.0;
+    long idx[MD_CHUNK];
+    bool ok[MD_CHUNK];
+    double s[MD_CHUNK], w0[MD_CHUNK];
 #pragma unroll
     for (int j = 0; j < MD_CHUNK; ++j) {
         const long t = (wave * MD_CHUNK + j) * 64 + lane;
-        if (t < nall) {
-            const long f = t / g.nown, i = t - f * g.nown;
-            const long idx = f * g.ntot + g.np + i;
-            double s = 0.0;
-            for (int q = 0; q < k; ++q) s += h[q] * V[(long)q * vstride + idx];
-            const double wn = w[idx] - s;
-            w[idx] = wn;
+        ok[j] = t < nall;
+        const long tt = ok[j] ? t : 0;
+        const long f = tt / g.nown, i = tt - f * g.nown;
+        idx[j] = f * g.ntot + g.np + i;
+        s[j] = 0.0;
+        w0[j] = w[idx[j]];
+    }
+    // MD_U vectors x MD_CHUNK entries = 16 independent loads in flight per lane (see k_multi_dot); the sum over q keeps
+    // its order, so the result is bitwise that of the one-vector-at-a-time loop
+    int q = 0;
+    for (; q + MD_U <= k; q += MD_U) {
+        double v[MD_U][MD_CHUNK], hq[MD_U];
+#pragma unroll
+        for (int u = 0; u < MD_U; ++u) {
+            hq[u] = h[q + u];
+#pragma unroll
+            for (int j = 0; j < MD_CHUNK; ++j) v[u][j] = V[(long)(q + u) * vstride + idx[j]];
+        }
+#pragma unroll
+        for (int u = 0; u < MD_U; ++u)
+#pragma unroll
+            for (int j = 0; j < MD_CHUNK; ++j) s[j] += hq[u] * v[u][j];
+    }
+    for (; q < k; ++q) {
+        const double hq = h[q];
+#pragma unroll
+        for (int j = 0; j < MD_CHUNK; ++j) s[j] += hq * V[(long)q * vstride + idx[j]];
+    }
+    double acc = 0.0;
+#pragma unroll
+    for (int j = 0; j < MD_CHUNK; ++j) {
+        if (ok[j]) {
+            const double wn = w0[j] - s[j];
+            w[idx[j]] = wn;
             acc += wn * wn;
         }
     }

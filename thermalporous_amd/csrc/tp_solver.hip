@@ -397,6 +397,26 @@ int fgmres(tp_ctx *c, const double *bvec, double *x, int *its_out, double *rnorm
             ++its;
             k = j + 1;
             res = std::fabs(gvec[j + 1]);
+            if (c->monitor) {
+                // ksp.buildResidual() per field (thermalmodel.py:44-74): x_j = Z y_j, r = b - J x_j, ||r_f||
+                std::vector<double> ym(k, 0.0), fn(B, 0.0);
+                std::vector<double> gm(gvec.begin(), gvec.begin() + k);
+                for (int i = k - 1; i >= 0; --i) {
+                    double s = gm[i];
+                    for (int q = i + 1; q < k; ++q) s -= H[(size_t)i * m + q] * ym[q];
+                    ym[i] = s / H[(size_t)i * m + i];
+                }
+                double *xm = c->w4.p, *rm = c->w2.p;                        // free between pc_apply calls
+                vec_copy(c, x, xm, nv);
+                multi_axpy(c, B, c->Z.p, nv, k, ym.data(), 1.0, xm);
+                if (c->dist) halo_exchange(c, g, xm, B, g.ntot);
+                resid_block_cols(c, c->J.p, bvec, xm, B, rm);
+                std::vector<const double *> fp(B);
+                for (int f = 0; f < B; ++f) fp[f] = rm + (long)f * g.ntot;
+                // (each field plane as a 1-field vector)
+                for (int f = 0; f < B; ++f) { const double *one[1] = {fp[f]}; multi_norm2sq(c, 1, 1, one, &fn[f]); fn[f] = std::sqrt(fn[f]); }
+                c->monitor(its, res, fn.data(), B, c->monitor_user);
+            }
             if (!std::isfinite(res)) { reason = -9; break; }               // KSP_DIVERGED_NANORINF
             if (res <= tol) { reason = 2; break; }
             if (hn == 0.0) { reason = 2; break; }
@@ -453,9 +473,8 @@ void newton(tp_ctx *c, tp_solve_info *info) {
         assemble(c, true, schur);
         ++nits;
         double nrm[3];
-        multi_dot(c, B, c->R.p, 0, 0, c->R.p, c->R.p, &nrm[0]);
-        multi_dot(c, B, dx->p, 0, 0, dx->p, dx->p, &nrm[1]);
-        multi_dot(c, B, c->u.p, 0, 0, c->u.p, c->u.p, &nrm[2]);
+        const double *nv3[3] = {c->R.p, dx->p, c->u.p};
+        multi_norm2sq(c, B, 3, nv3, nrm);                       // one reduction, one all-reduce, one host sync
         fnorm = std::sqrt(nrm[0]);
         const double snorm = std::sqrt(nrm[1]), xnorm = std::sqrt(nrm[2]);
         if (!std::isfinite(fnorm)) reason = -4;

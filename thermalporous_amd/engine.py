@@ -60,7 +60,7 @@ API_SYMBOLS = (
     "tp_set_field", "tp_finalize_fields", "tp_set_sources", "tp_set_state", "tp_get_state", "tp_set_old_state",
     "tp_set_dt", "tp_get_old_state", "tp_restore_state", "tp_saturation_range", "tp_clamp_saturation",
     "tp_residual", "tp_jacobian", "tp_get_residual", "tp_export_jacobian", "tp_export_schur",
-    "tp_well_rates", "tp_vec_create", "tp_vec_create_batch", "tp_vec_dot_batch", "tp_vec_axpy_batch", "tp_vec_norm2", "tp_vec_set", "tp_vec_get", "tp_vec_copy_residual", "tp_spmv", "tp_pc_setup",
+    "tp_well_rates", "tp_vec_create", "tp_vec_create_batch", "tp_vec_dot_batch", "tp_vec_axpy_batch", "tp_vec_norm2", "tp_set_ksp_monitor", "tp_vec_set", "tp_vec_get", "tp_vec_copy_residual", "tp_spmv", "tp_pc_setup",
     "tp_pc_apply", "tp_stage1_update", "tp_stage1_apply", "tp_ilu0_factor", "tp_ilu0_solve", "tp_amg_setup",
     "tp_amg_vcycle", "tp_schur_apply", "tp_fgmres", "tp_newton_solve", "tp_time_kernel", "tp_amg_info", "tp_amg_layout",
 )
@@ -378,6 +378,17 @@ class HipEngine:
         out = C.c_double()
         self._ck(self.lib.tp_vec_norm2(self.ctx, self.vec(x), C.byref(out)))
         return out.value
+
+    def set_ksp_monitor(self, fn):
+        """fn(its, rnorm, field_norms) at every FGMRES iteration (the reference's ksp_monitor_residuals monitor,
+        thermalmodel.py:44-74); None removes it."""
+        proto = C.CFUNCTYPE(None, C.c_int32, C.c_double, C.POINTER(C.c_double), C.c_int32, C.c_void_p)
+        if fn is None:
+            self._monitor_cb = None
+            self._ck(self.lib.tp_set_ksp_monitor(self.ctx, C.cast(None, proto), None))
+            return
+        self._monitor_cb = proto(lambda its, rn, fnp, nf, user: fn(int(its), float(rn), [fnp[i] for i in range(nf)]))
+        self._ck(self.lib.tp_set_ksp_monitor(self.ctx, self._monitor_cb, None))
 
     def spmv(self, x, y):
         self._ck(self.lib.tp_spmv(self.ctx, self.vec(x), self.vec(y)))

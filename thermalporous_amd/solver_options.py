@@ -21,7 +21,7 @@ experimental FAS nonlinear preconditioner (twophase.py:927; needs mesh hierarchi
 
 # keys that only print / name the matrix type: no effect on the arithmetic
 _IGNORED = {"snes_monitor", "snes_converged_reason", "ksp_converged_reason", "ksp_view", "snes_view", "ksp_monitor",
-            "ksp_monitor_residuals"}
+            "ksp_monitor_residuals"}      # (ksp_monitor_residuals is honoured by ThermalModel.init_solver, like the reference)
 
 # every PETSc key the hot path CONSUMES (checked against the value it implements) -- anything else raises
 _VCYCLE_SUFFIXES = {"ksp_type": "preonly", "pc_type": "hypre", "pc_hypre_type": "boomeramg",

@@ -114,6 +114,15 @@ class ThermalModel:
         self.u.bind(self, "u")
         self.u_.bind(self, "u_")
         self.solver = NonlinearSolver(self)
+        if "ksp_monitor_residuals" in self.solver_parameters and hasattr(self.engine, "set_ksp_monitor"):
+            # per-equation norms of ksp.buildResidual() at every Krylov iteration (thermalmodel.py:44-74)
+            names = (("Pressure", "Energy", "Oil") if self.name == "Two-phase" else ("Mass", "Energy"))
+
+            def my_monitor(its, rnorm, field_norms):
+                if self.comm.rank == 0 and self.verbosity:
+                    for nm, v in zip(names, field_norms):
+                        print("  --> %s equation residual: %s" % (nm, v))
+            self.engine.set_ksp_monitor(my_monitor)
 
     def _to_internal(self, f):
         return field_major_to_internal(f, self.geo, self.spec["axes"], self.nfields)
