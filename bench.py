@@ -271,9 +271,20 @@ def main():
     def line(bytes_per_cell, ms):
         gbs = bytes_per_cell*ncell_local/(ms*1e-3)/1e9
         return {"bytes_per_cell": bytes_per_cell, "avg_ms": ms, "achieved_GBs": gbs, "frac": gbs/HBM_PEAK_GBS}
+    # one classical Gram-Schmidt step at k = 16 basis vectors: VecMDot reads 16 V + w, VecMAXPY reads 16 V + w and writes w
+    try:
+        km["gram_schmidt_k16_ms"] = eng.time_kernel(7, 30)
+        gs = line((2*16 + 3)*eng.b*8, km["gram_schmidt_k16_ms"])
+    except Exception:                 # (no solve has used 17 basis vectors yet: nothing to time)
+        gs = None
     others = {"spmv_block": line(SPMV_BYTES_PER_CELL[key], km["spmv_ms"]),
               "assembly_residual_jacobian": line(ASM_BYTES_PER_CELL[key], km["assembly_ms"]),
               "ilu0_factor": line(FACTOR_BYTES_PER_CELL[key], km["ilu_factor_ms"])}
+    if gs is not None:
+        others["gram_schmidt_k16"] = gs
+    # the reference's own rate definition (thermalmodel.py:395-403): iterations over the summed wall time of the
+    # SUCCESSFUL solver.solve() calls of the timed steps (a failed solve's time is not in `timings` there either)
+    t_ok = float(sum(model.timings[-args.steps:])) if len(model.timings) >= args.steps else None
     if rank != 0:
         return
     ilu = line(SPMV_BYTES_PER_CELL[key], km["ilu_solve_ms"])
@@ -317,6 +328,9 @@ def main():
             "newton_its": nits, "fgmres_its": lits, "failed_solves": model.failed_solves - f0,
             "dt_days": [float(dts.min()), float(dts.max())],
             "ms_per_fgmres_it": it_ms,
+            "reference_style_rates": None if not t_ok else {"newton_per_s": nits/t_ok, "fgmres_per_s": lits/t_ok,
+                                                           "note": "sum(nits)/sum(timings) of successful solves only, "
+                                                                   "as thermalmodel.py:395-403 prints it"},
             "ramp": ramp,
             "slabs": "1-D along the slab axis" if world > 1 else "none",
             "kernels_ms": km,

@@ -195,7 +195,8 @@ int tp_newton_solve(tp_ctx *ctx, tp_solve_info *info);
 
 /* measurement hooks for bench.py: average device time (ms, HIP events on the context's stream)
  * of `reps` launches of one hot kernel.  which: 0 block SpMV, 1 ILU solve, 2 AMG V-cycle (pressure),
- * 3 assembly (residual+Jacobian), 4 full pc_apply, 5 pc_setup, 6 ILU factorisation. */
+ * 3 assembly (residual+Jacobian), 4 full pc_apply, 5 pc_setup, 6 ILU factorisation, 7 one classical Gram-Schmidt
+ * step against 16 basis vectors (VecMDot + VecMAXPY + VecNorm; needs a Krylov basis from an earlier solve). */
 int tp_time_kernel(tp_ctx *ctx, int32_t which, int32_t reps, double *ms_avg);
 int tp_amg_info(tp_ctx *ctx, int32_t which, int32_t *nlevels, double *op_complexity);
 /* coarsening axis of every level (internal axis numbering, 2 = slab axis) and how many of the top levels are

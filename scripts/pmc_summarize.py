@@ -15,7 +15,7 @@ import statistics
 import sys
 
 CELLS = 60*220*85
-KEEP = ("k_assemble", "k_spmv_block", "k_ilu_solve", "k_ilu_factor", "k_ilu_gather", "k_spmv_scalar")
+KEEP = ("k_assemble", "k_spmv_block", "k_ilu_solve", "k_ilu_factor", "k_ilu_gather", "k_spmv_scalar", "k_multi_dot", "k_multi_axpy_norm")
 
 
 def collect(d, counter):

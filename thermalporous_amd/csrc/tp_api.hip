@@ -768,6 +768,12 @@ int tp_time_kernel(tp_ctx *c, int32_t which, int32_t reps, double *ms_avg) {
             case 4: pc_apply(c, c->R.p, c->dx.p); break;
             case 5: pc_setup(c); break;
             case 6: ilu_factor(c); break;
+            case 7: {       // one classical Gram-Schmidt step against 16 basis vectors (VecMDot + VecMAXPY + norm)
+                TP_REQUIRE(c->gs_cap >= 17, "Krylov basis smaller than 17 vectors: run a solve first");
+                std::vector<double> hh(18);
+                orthogonalize(c, c->b, c->V.p, (long)c->b * c->g.ntot, 16, c->w2.p, hh.data());
+                break;
+            }
             default: throw Error("unknown kernel id");
         }
     };

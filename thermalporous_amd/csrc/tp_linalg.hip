@@ -3,6 +3,7 @@
 // consecutive cells, every matrix plane streamed exactly once per product.
 #include "tp_common.hpp"
 #include <algorithm>
+#include <cstdlib>
 
 namespace tp {
 
@@ -44,7 +45,6 @@ void vec_scale_to(tp_ctx *c, int nf, double a, const double *x, double *y) {
 // Each wave owns a chunk of owned entries (CHUNK per lane kept in registers), loops over the k basis
 // vectors and reduces with DPP shuffles; per-wave partials go to gs_partial[i][wave], a second tiny
 // kernel sums them in a fixed order (deterministic).  The k-th extra output is <w2, w2>.
-constexpr int MD_CHUNK = 4;
 
 __device__ __forceinline__ double wave_sum(double v) {
 #pragma unroll
@@ -60,9 +60,11 @@ __device__ __forceinline__ double wave_sum(double v) {
 // unchanged (bitwise identical results).
 constexpr int MD_U = 4;
 
+template <int CH>
 __global__ __launch_bounds__(256) void k_multi_dot(GridDev g, int nf, const double *__restrict__ V, long vstride, int k,
                                                    const double *__restrict__ w, const double *__restrict__ w2,
                                                    double *__restrict__ partial, long nwaves) {
+    constexpr int MD_CHUNK = CH;
     const long wave = ((long)blockIdx.x * blockDim.x + threadIdx.x) >> 6;
     const int lane = threadIdx.x & 63;
     if (wave >= nwaves) return;
@@ -143,10 +145,20 @@ __global__ __launch_bounds__(1024) void k_reduce_partials(const double *__restri
     }
 }
 
+// entries per lane in the Gram-Schmidt kernels: 4 or 8 (TP_MD_CHUNK; 8 halves the cross-lane reductions per byte)
+static int md_chunk() {
+    static const int ch = (getenv("TP_MD_CHUNK") && atoi(getenv("TP_MD_CHUNK")) == 4) ? 4 : 8;
+    return ch;
+}
 static long md_nwaves(const tp_ctx *c, int nf) {
     const long nall = c->g.nown * nf;
-    return (nall + 64L * MD_CHUNK - 1) / (64L * MD_CHUNK);
+    return (nall + 64L * md_chunk() - 1) / (64L * md_chunk());
 }
+#define TP_MD_LAUNCH(KERNEL, ...)                                                                              \
+    do {                                                                                                       \
+        if (md_chunk() == 4) hipLaunchKernelGGL(KERNEL<4>, __VA_ARGS__);                                       \
+        else hipLaunchKernelGGL(KERNEL<8>, __VA_ARGS__);                                                       \
+    } while (0)
 
 void multi_dot(tp_ctx *c, int nf, const double *V, long vstride, int k, const double *w, const double *w2,
                double *host_out) {
@@ -154,8 +166,8 @@ void multi_dot(tp_ctx *c, int nf, const double *V, long vstride, int k, const do
     const int nout = k + (w2 ? 1 : 0);
     if ((long)c->gs_partial.n < (long)nout * nw) c->gs_partial.alloc((size_t)(nout + 32) * nw);
     if ((long)c->red_out.n < nout) c->red_out.alloc(nout + 64);
-    hipLaunchKernelGGL(k_multi_dot, grid_for(nw * 64), dim3(256), 0, c->stream, c->g, nf, V, vstride, k, w, w2,
-                       c->gs_partial.p, nw);
+    TP_MD_LAUNCH(k_multi_dot, grid_for(nw * 64), dim3(256), 0, c->stream, c->g, nf, V, vstride, k, w, w2,
+                 c->gs_partial.p, nw);
     hipLaunchKernelGGL(k_reduce_partials, dim3(nout), dim3(1024), 0, c->stream, c->gs_partial.p, nw, c->red_out.p);
     TP_HIP(hipGetLastError());
     allreduce_sum(c, c->red_out.p, nout);
@@ -170,8 +182,8 @@ void multi_norm2sq(tp_ctx *c, int nf, int nvec, const double *const *x, double *
     if ((long)c->gs_partial.n < (long)nvec * nw) c->gs_partial.alloc((size_t)(nvec + 32) * nw);
     if ((long)c->red_out.n < nvec) c->red_out.alloc(nvec + 64);
     for (int i = 0; i < nvec; ++i)
-        hipLaunchKernelGGL(k_multi_dot, grid_for(nw * 64), dim3(256), 0, c->stream, c->g, nf, x[i], 0L, 0, x[i], x[i],
-                           c->gs_partial.p + (long)i * nw, nw);
+        TP_MD_LAUNCH(k_multi_dot, grid_for(nw * 64), dim3(256), 0, c->stream, c->g, nf, x[i], 0L, 0, x[i], x[i],
+                     c->gs_partial.p + (long)i * nw, nw);
     hipLaunchKernelGGL(k_reduce_partials, dim3(nvec), dim3(1024), 0, c->stream, c->gs_partial.p, nw, c->red_out.p);
     TP_HIP(hipGetLastError());
     allreduce_sum(c, c->red_out.p, nvec);
@@ -220,9 +232,11 @@ void multi_axpy(tp_ctx *c, int nf, const double *V, long vstride, int k, const d
 // ---- one Gram-Schmidt step with a single host sync -------------------------------------------------
 // h = V^T w (k dots) ; w -= V h ; ||w||^2 -- the coefficients never leave the device between the dot and
 // the update, so an FGMRES iteration pays one D2H copy + sync here instead of three.
+template <int CH>
 __global__ __launch_bounds__(256) void k_multi_axpy_norm(GridDev g, int nf, const double *__restrict__ V, long vstride,
                                                          int k, const double *__restrict__ h, double *w,
                                                          double *__restrict__ partial, long nwaves) {
+    constexpr int MD_CHUNK = CH;
     const long wave = ((long)blockIdx.x * blockDim.x + threadIdx.x) >> 6;
     const int lane = threadIdx.x & 63;
     if (wave >= nwaves) return;
@@ -278,12 +292,12 @@ void orthogonalize(tp_ctx *c, int nf, const double *V, long vstride, int k, doub
     const long nw = md_nwaves(c, nf);
     if ((long)c->gs_partial.n < (long)(k + 1) * nw) c->gs_partial.alloc((size_t)(k + 33) * nw);
     if ((long)c->red_out.n < k + 1) c->red_out.alloc(k + 65);
-    hipLaunchKernelGGL(k_multi_dot, grid_for(nw * 64), dim3(256), 0, c->stream, c->g, nf, V, vstride, k, w,
-                       (const double *)nullptr, c->gs_partial.p, nw);
+    TP_MD_LAUNCH(k_multi_dot, grid_for(nw * 64), dim3(256), 0, c->stream, c->g, nf, V, vstride, k, w,
+                 (const double *)nullptr, c->gs_partial.p, nw);
     hipLaunchKernelGGL(k_reduce_partials, dim3(k), dim3(1024), 0, c->stream, c->gs_partial.p, nw, c->red_out.p);
     allreduce_sum(c, c->red_out.p, k);
-    hipLaunchKernelGGL(k_multi_axpy_norm, grid_for(nw * 64), dim3(256), 0, c->stream, c->g, nf, V, vstride, k,
-                       c->red_out.p, w, c->gs_partial.p, nw);
+    TP_MD_LAUNCH(k_multi_axpy_norm, grid_for(nw * 64), dim3(256), 0, c->stream, c->g, nf, V, vstride, k,
+                 c->red_out.p, w, c->gs_partial.p, nw);
     hipLaunchKernelGGL(k_reduce_partials, dim3(1), dim3(1024), 0, c->stream, c->gs_partial.p, nw, c->red_out.p + k);
     TP_HIP(hipGetLastError());
     allreduce_sum(c, c->red_out.p + k, 1);
