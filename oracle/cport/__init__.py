@@ -95,7 +95,8 @@ class CPortEngine:
             from ..engine import blocks_to_tile
             o["ilu_tile"] = blocks_to_tile(spec["n"], o["bjacobi_blocks"])
         if o.get("ilu_tile") is None:
-            o["ilu_tile"] = (1 << 30, 32, 1) if int(spec["n"][2]) == 1 else (1 << 30, 8, 8)
+            from ..engine import default_ilu_tile
+            o["ilu_tile"] = default_ilu_tile(spec["n"], nslabs=int(o.get("nslabs", 1)))
         self.nph = int(spec["nphase"])
         self.b = self.nph + 1
         n = tuple(int(v) for v in spec["n"])

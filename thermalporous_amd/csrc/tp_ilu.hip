@@ -59,6 +59,8 @@ __device__ __forceinline__ void inv_block<3>(const double (&A)[3][3], double (&I
 struct IluGeom {
     GridDev g;
     int t0, t1, t2, nt0, nt1, nt2, nsteps;
+    int nl;        // lanes of a wave that carry a column: t1*t2 <= 64
+    int rs;        // doubles per chunk row = 2*nl (one double2 per live lane): rows are as wide as the tile, not the wave
 };
 
 // number of double2 pairs per chunk
@@ -134,7 +136,7 @@ __global__ __launch_bounds__(64 * ILU_SEG) void k_ilu_gather(IluGeom G, const do
         double2 o;
         o.x = v[2 * u];
         o.y = v[2 * u + 1];
-        reinterpret_cast<double2 *>(Jt + (((long)tile * ns + s) * L::PJ + P0 + u) * 128)[lane] = o;
+        if (lane < G.nl) reinterpret_cast<double2 *>(Jt + (((long)tile * ns + s) * L::PJ + P0 + u) * G.rs)[lane] = o;
     }
 }
 
@@ -143,6 +145,8 @@ __global__ __launch_bounds__(64) void k_ilu_factor(IluGeom G, const double *__re
                                                    double *bwd) {
     using L = IluLayout<B>;
     const int tile = blockIdx.x, lane = threadIdx.x;
+    const int la = lane < G.nl ? lane : G.nl - 1;      // idle lanes (>= t1*t2) load a live lane's data and store nothing
+    const bool live = lane < G.nl;
     const TileInfo ti = tile_info(G, tile, lane);
     const int ns = G.nsteps;
     double Dp[B][B];                       // D~^-1 of this lane's previous cell (axis-0 lower neighbour)
@@ -170,11 +174,11 @@ __global__ __launch_bounds__(64) void k_ilu_factor(IluGeom G, const double *__re
         int l0;
         long c;
         k.ok = tile_cell(G, ti, s, l0, c);
-        const double2 *ch = reinterpret_cast<const double2 *>(Jt + ((long)tile * ns + s) * (L::PJ * 128)) + lane;
+        const double2 *ch = reinterpret_cast<const double2 *>(Jt + ((long)tile * ns + s) * ((long)L::PJ * G.rs)) + la;
         double v[2 * L::PJ];
 #pragma unroll
         for (int p = 0; p < L::PJ; ++p) {
-            const double2 t = ch[p * 64];
+            const double2 t = ch[p * G.nl];
             v[2 * p] = t.x;
             v[2 * p + 1] = t.y;
         }
@@ -211,8 +215,8 @@ __global__ __launch_bounds__(64) void k_ilu_factor(IluGeom G, const double *__re
                 Amc[2][r][q] = __shfl_up(Aprev[2][r][q], G.t1, 64);
             }
         double D[B][B], Di[B][B];
-        double *fch = fwd + ((long)tile * ns + s) * (L::PF * 128);
-        double *bch = bwd + ((long)tile * ns + s) * (L::PB * 128);
+        double *fch = fwd + ((long)tile * ns + s) * ((long)L::PF * G.rs);
+        double *bch = bwd + ((long)tile * ns + s) * ((long)L::PB * G.rs);
 #pragma unroll
         for (int r = 0; r < B; ++r)
 #pragma unroll
@@ -238,10 +242,10 @@ __global__ __launch_bounds__(64) void k_ilu_factor(IluGeom G, const double *__re
                     for (int t = 0; t < B; ++t) v += Bm[r][t] * Amc[a][t][q];
                     D[r][q] -= v;
                     const int e = (a * B + r) * B + q;
-                    fch[(e >> 1) * 128 + lane * 2 + (e & 1)] = Bm[r][q];
+                    if (live) fch[(e >> 1) * G.rs + lane * 2 + (e & 1)] = Bm[r][q];
                 }
         }
-        if (L::NEF & 1) fch[(L::NEF >> 1) * 128 + lane * 2 + 1] = 0.0;    // padding half of the last pair
+        if ((L::NEF & 1) && live) fch[(L::NEF >> 1) * G.rs + lane * 2 + 1] = 0.0;    // padding half of the last pair
         if (k.ok) {
             inv_block<B>(D, Di);
         } else {
@@ -261,14 +265,14 @@ __global__ __launch_bounds__(64) void k_ilu_factor(IluGeom G, const double *__re
 #pragma unroll
                     for (int t = 0; t < B; ++t) v += Di[r][t] * k.Aup[a][t][q];
                     const int e = (a * B + r) * B + q;
-                    bch[(e >> 1) * 128 + lane * 2 + (e & 1)] = v;
+                    if (live) bch[(e >> 1) * G.rs + lane * 2 + (e & 1)] = v;
                 }
 #pragma unroll
         for (int r = 0; r < B; ++r)
 #pragma unroll
             for (int q = 0; q < B; ++q) {
                 const int e = (3 * B + r) * B + q;
-                bch[(e >> 1) * 128 + lane * 2 + (e & 1)] = Di[r][q];
+                if (live) bch[(e >> 1) * G.rs + lane * 2 + (e & 1)] = Di[r][q];
                 Dp[r][q] = Di[r][q];
             }
 #pragma unroll
@@ -289,12 +293,12 @@ __global__ __launch_bounds__(64) void k_ilu_factor(IluGeom G, const double *__re
     }
 }
 
-// one chunk = NP double2 per lane, coalesced
+// one chunk = NP double2 per live lane, coalesced (rows of nl double2)
 template <int NP>
-__device__ __forceinline__ void load_chunk(const double *__restrict__ ch, int lane, double2 (&v)[NP]) {
+__device__ __forceinline__ void load_chunk(const double *__restrict__ ch, int lane, int nl, double2 (&v)[NP]) {
     const double2 *p = reinterpret_cast<const double2 *>(ch) + lane;
 #pragma unroll
-    for (int i = 0; i < NP; ++i) v[i] = p[i * 64];
+    for (int i = 0; i < NP; ++i) v[i] = p[i * nl];
 }
 template <int NP>
 __device__ __forceinline__ double chunk_get(const double2 (&v)[NP], int e) {
@@ -305,17 +309,23 @@ __device__ __forceinline__ double chunk_get(const double2 (&v)[NP], int e) {
 // Three register buffers form a prefetch ring: while step s computes from one buffer the chunks of
 // steps s+1 and s+2 are in flight into the other two, and the buffer just consumed is refilled with
 // step s+3 -- a single wave per CU keeps ~40 KB of HBM reads outstanding.
-template <int B, bool DEPTH2>
+// YLDS: the intermediate vector y of the tile (nsteps x B x 64 doubles, 147 KB on C4) stays in the CU's LDS between
+// the two sweeps instead of going through HBM (a write, a read and their row padding: 10 % of the kernel's traffic).
+template <int B, bool DEPTH2, bool YLDS>
 __global__ __launch_bounds__(64) void k_ilu_solve(IluGeom G, const double *__restrict__ fwd,
                                                   const double *__restrict__ bwd, const double *__restrict__ rhs,
                                                   double *__restrict__ ytmp, double *x, const double *addto,
                                                   int nadd) {
     using L = IluLayout<B>;
+    extern __shared__ double ylds[];       // [step][field][lane] when YLDS
     const int tile = blockIdx.x, lane = threadIdx.x;
+    const int la = lane < G.nl ? lane : G.nl - 1;      // idle lanes (>= t1*t2) shadow a live lane's loads
+    const bool live = lane < G.nl;
     const long nt = G.g.ntot;
     const TileInfo ti = tile_info(G, tile, lane);
     const long chunk0 = (long)tile * G.nsteps;
     const int ns = G.nsteps;
+    const long rowF = (long)L::PF * G.rs, rowB = (long)L::PB * G.rs, rowY = (long)L::PY * G.rs;
     constexpr int RING = DEPTH2 ? 3 : 2;
     int l0;
     long c;
@@ -329,7 +339,7 @@ __global__ __launch_bounds__(64) void k_ilu_solve(IluGeom G, const double *__res
         bool okk[RING];
         auto load = [&](int k, int step) {
             okk[k] = tile_cell(G, ti, step, l0, c);
-            load_chunk<L::PF>(fwd + (chunk0 + step) * (L::PF * 128), lane, buf[k]);
+            load_chunk<L::PF>(fwd + (chunk0 + step) * rowF, la, G.nl, buf[k]);
 #pragma unroll
             for (int r = 0; r < B; ++r) rr[k][r] = okk[k] ? rhs[(long)r * nt + c] : 0.0;
         };
@@ -349,11 +359,12 @@ __global__ __launch_bounds__(64) void k_ilu_solve(IluGeom G, const double *__res
                 for (int r = 0; r < B; ++r)
 #pragma unroll
                     for (int q = 0; q < B; ++q) y[r] -= chunk_get<L::PF>(buf[k], (a * B + r) * B + q) * yn[a][q];
-            double *ych = ytmp + (chunk0 + s) * (L::PY * 128);
+            double *ych = ytmp + (chunk0 + s) * rowY;
 #pragma unroll
             for (int r = 0; r < B; ++r) {
                 y[r] = okk[k] ? y[r] : 0.0;
-                ych[(r >> 1) * 128 + lane * 2 + (r & 1)] = y[r];
+                if (YLDS) ylds[((long)s * B + r) * 64 + lane] = y[r];
+                else if (live) ych[(r >> 1) * G.rs + lane * 2 + (r & 1)] = y[r];
                 yp[r] = y[r];
             }
         };
@@ -375,33 +386,33 @@ __global__ __launch_bounds__(64) void k_ilu_solve(IluGeom G, const double *__res
         double xp[B];
 #pragma unroll
         for (int r = 0; r < B; ++r) xp[r] = 0.0;
-        double2 buf[RING][L::PB], ybuf[RING][L::PY];
+        double2 buf[RING][L::PB], ybuf[RING][YLDS ? 1 : L::PY];
         double aa[RING][B];
         bool okk[RING];
         long cc[RING];
         auto load = [&](int k, int step) {
             okk[k] = tile_cell(G, ti, step, l0, c);
             cc[k] = c;
-            load_chunk<L::PB>(bwd + (chunk0 + step) * (L::PB * 128), lane, buf[k]);
-            load_chunk<L::PY>(ytmp + (chunk0 + step) * (L::PY * 128), lane, ybuf[k]);
+            load_chunk<L::PB>(bwd + (chunk0 + step) * rowB, la, G.nl, buf[k]);
+            if (!YLDS) load_chunk<(YLDS ? 1 : L::PY)>(ytmp + (chunk0 + step) * rowY, la, G.nl, ybuf[k]);
 #pragma unroll
             for (int r = 0; r < B; ++r)      // fields >= nadd of addto are taken as zero (never read)
                 aa[k][r] = (okk[k] && addto && r < nadd) ? addto[(long)r * nt + c] : 0.0;
         };
-        auto step = [&](int k) {
-            double xn[3][B], xv[B];
+        auto step = [&](int k, int s) {
+            double xn[3][B], xv[B], yv[B];
 #pragma unroll
             for (int r = 0; r < B; ++r) {
                 xn[0][r] = xp[r];
                 xn[1][r] = __shfl_down(xp[r], 1, 64);
                 xn[2][r] = __shfl_down(xp[r], G.t1, 64);
+                yv[r] = YLDS ? ylds[((long)s * B + r) * 64 + lane] : chunk_get<(YLDS ? 1 : L::PY)>(ybuf[k], r);
             }
 #pragma unroll
             for (int r = 0; r < B; ++r) {
                 double v = 0.0;
 #pragma unroll
-                for (int q = 0; q < B; ++q)
-                    v += chunk_get<L::PB>(buf[k], (3 * B + r) * B + q) * chunk_get<L::PY>(ybuf[k], q);
+                for (int q = 0; q < B; ++q) v += chunk_get<L::PB>(buf[k], (3 * B + r) * B + q) * yv[q];
                 xv[r] = v;
             }
 #pragma unroll
@@ -418,7 +429,7 @@ __global__ __launch_bounds__(64) void k_ilu_solve(IluGeom G, const double *__res
             }
         };
         // the forward sweep's y of the last steps may still be in flight as stores: same-lane same-address
-        // loads are ordered after them by the memory pipeline
+        // loads are ordered after them by the memory pipeline (YLDS: same lane, same LDS address, program order)
 #pragma unroll
         for (int k = 0; k < RING; ++k)
             if (ns - 1 - k >= 0) load(k, ns - 1 - k);
@@ -426,7 +437,7 @@ __global__ __launch_bounds__(64) void k_ilu_solve(IluGeom G, const double *__res
 #pragma unroll
             for (int k = 0; k < RING; ++k) {
                 if (s - k >= 0) {
-                    step(k);
+                    step(k, s - k);
                     if (s - k - RING >= 0) load(k, s - k - RING);
                 }
             }
@@ -440,17 +451,19 @@ static IluGeom geom_of(const tp_ctx *c) {
     G.t0 = c->ilu.t0; G.t1 = c->ilu.t1; G.t2 = c->ilu.t2;
     G.nt0 = c->ilu.nt0; G.nt1 = c->ilu.nt1; G.nt2 = c->ilu.nt2;
     G.nsteps = c->ilu.nsteps;
+    G.nl = G.t1 * G.t2;
+    G.rs = 2 * G.nl;
     return G;
 }
 
 template <int B>
 static void alloc_factor(IluData &d) {
     using L = IluLayout<B>;
-    const size_t chunks = (size_t)d.ntiles * d.nsteps;
-    d.fwd.alloc(chunks * L::PF * 128);
-    d.bwd.alloc(chunks * L::PB * 128);
-    d.ytmp.alloc(chunks * L::PY * 128);
-    d.jt.alloc(chunks * L::PJ * 128);
+    const size_t chunks = (size_t)d.ntiles * d.nsteps, rs = (size_t)2 * d.t1 * d.t2;      // rows as wide as the tile
+    d.fwd.alloc(chunks * L::PF * rs);
+    d.bwd.alloc(chunks * L::PB * rs);
+    d.ytmp.alloc(chunks * L::PY * rs);
+    d.jt.alloc(chunks * L::PJ * rs);
 }
 
 void ilu_setup(tp_ctx *c) {
@@ -500,11 +513,29 @@ void ilu_solve(tp_ctx *c, const double *r, double *x, const double *addto, int n
     TP_REQUIRE(c->ilu.slots > 0, "ILU not factored");
     const IluGeom G = geom_of(c);
     static const bool deep = !(getenv("TP_ILU_DEPTH") && atoi(getenv("TP_ILU_DEPTH")) == 1);
-#define TP_ILU_LAUNCH(BB, DD)                                                                                  \
-    hipLaunchKernelGGL((k_ilu_solve<BB, DD>), dim3(c->ilu.ntiles), dim3(64), 0, c->stream, G, c->ilu.fwd.p, \
-                       c->ilu.bwd.p, r, c->ilu.ytmp.p, x, addto, nadd)
-    if (c->b == 3) { if (deep) TP_ILU_LAUNCH(3, true); else TP_ILU_LAUNCH(3, false); }
-    else           { if (deep) TP_ILU_LAUNCH(2, true); else TP_ILU_LAUNCH(2, false); }
+    static const bool ylds_on = !(getenv("TP_ILU_YLDS") && atoi(getenv("TP_ILU_YLDS")) == 0);
+    // y in LDS when the tile's whole intermediate vector fits one CU's 160 KB (one workgroup per CU then)
+    const size_t ybytes = (size_t)G.nsteps * c->b * 64 * sizeof(double);
+    const bool ylds = ylds_on && ybytes <= 152 * 1024;
+    static bool attr_set = false;
+    if (ylds && !attr_set) {
+        const int lim = 152 * 1024;
+        TP_HIP(hipFuncSetAttribute(reinterpret_cast<const void *>(&k_ilu_solve<3, true, true>), hipFuncAttributeMaxDynamicSharedMemorySize, lim));
+        TP_HIP(hipFuncSetAttribute(reinterpret_cast<const void *>(&k_ilu_solve<3, false, true>), hipFuncAttributeMaxDynamicSharedMemorySize, lim));
+        TP_HIP(hipFuncSetAttribute(reinterpret_cast<const void *>(&k_ilu_solve<2, true, true>), hipFuncAttributeMaxDynamicSharedMemorySize, lim));
+        TP_HIP(hipFuncSetAttribute(reinterpret_cast<const void *>(&k_ilu_solve<2, false, true>), hipFuncAttributeMaxDynamicSharedMemorySize, lim));
+        attr_set = true;
+    }
+#define TP_ILU_LAUNCH(BB, DD, YY)                                                                                     \
+    hipLaunchKernelGGL((k_ilu_solve<BB, DD, YY>), dim3(c->ilu.ntiles), dim3(64), (YY) ? ybytes : 0, c->stream, G,     \
+                       c->ilu.fwd.p, c->ilu.bwd.p, r, c->ilu.ytmp.p, x, addto, nadd)
+#define TP_ILU_PICK(BB)                                                                                               \
+    do {                                                                                                              \
+        if (deep) { if (ylds) TP_ILU_LAUNCH(BB, true, true); else TP_ILU_LAUNCH(BB, true, false); }                   \
+        else      { if (ylds) TP_ILU_LAUNCH(BB, false, true); else TP_ILU_LAUNCH(BB, false, false); }                 \
+    } while (0)
+    if (c->b == 3) TP_ILU_PICK(3); else TP_ILU_PICK(2);
+#undef TP_ILU_PICK
 #undef TP_ILU_LAUNCH
     TP_HIP(hipGetLastError());
 }
