@@ -60,7 +60,7 @@ struct IluGeom {
     GridDev g;
     int t0, t1, t2, nt0, nt1, nt2, nsteps;
     int nl;        // lanes of a wave that carry a column: t1*t2 <= 64
-    int rs;        // doubles per chunk row = 2*nl (one double2 per live lane): rows are as wide as the tile, not the wave
+    int rs;        // doubles per chunk row: 2*nl when the rows are as wide as the tile (CP kernels), else 128
 };
 
 // number of double2 pairs per chunk
@@ -109,10 +109,11 @@ __device__ __forceinline__ bool tile_cell(const IluGeom &G, const TileInfo &t, i
 // zeros, so the factorisation needs no masks.
 constexpr int ILU_SEG = 16;      // steps per workgroup
 constexpr int ILU_PPT = 1;       // entry pairs per thread
-template <int B>
+template <int B, bool CP>
 __global__ __launch_bounds__(64 * ILU_SEG) void k_ilu_gather(IluGeom G, const double *__restrict__ J,
                                                              double *__restrict__ Jt) {
     using L = IluLayout<B>;
+    const int NL = CP ? G.nl : 64, RS = CP ? G.rs : 128;
     const int tile = blockIdx.x, P0 = blockIdx.y * ILU_PPT, s = blockIdx.z * ILU_SEG + (threadIdx.x >> 6),
               lane = threadIdx.x & 63;
     const int ns = G.nsteps;
@@ -136,17 +137,21 @@ __global__ __launch_bounds__(64 * ILU_SEG) void k_ilu_gather(IluGeom G, const do
         double2 o;
         o.x = v[2 * u];
         o.y = v[2 * u + 1];
-        if (lane < G.nl) reinterpret_cast<double2 *>(Jt + (((long)tile * ns + s) * L::PJ + P0 + u) * G.rs)[lane] = o;
+        if (!CP || lane < NL) reinterpret_cast<double2 *>(Jt + (((long)tile * ns + s) * L::PJ + P0 + u) * RS)[lane] = o;
     }
 }
 
-template <int B>
+template <int B, bool CP>
 __global__ __launch_bounds__(64) void k_ilu_factor(IluGeom G, const double *__restrict__ Jt, double *fwd,
                                                    double *bwd) {
     using L = IluLayout<B>;
     const int tile = blockIdx.x, lane = threadIdx.x;
-    const int la = lane < G.nl ? lane : G.nl - 1;      // idle lanes (>= t1*t2) load a live lane's data and store nothing
-    const bool live = lane < G.nl;
+    const int NL = CP ? G.nl : 64, RS = CP ? G.rs : 128;
+    // idle lanes (>= t1*t2) load a live lane's data and store nothing.  With wave-wide rows every lane is live and both
+    // are compile-time facts: a (never false) run-time `if (live)` around the stores is a divergent branch to the
+    // compiler, which then drains ALL outstanding loads (s_waitcnt vmcnt(0)) at every step -- measured +40 % on C1
+    const int la = CP ? (lane < NL ? lane : NL - 1) : lane;
+    const bool live = CP ? lane < NL : true;
     const TileInfo ti = tile_info(G, tile, lane);
     const int ns = G.nsteps;
     double Dp[B][B];                       // D~^-1 of this lane's previous cell (axis-0 lower neighbour)
@@ -174,11 +179,11 @@ __global__ __launch_bounds__(64) void k_ilu_factor(IluGeom G, const double *__re
         int l0;
         long c;
         k.ok = tile_cell(G, ti, s, l0, c);
-        const double2 *ch = reinterpret_cast<const double2 *>(Jt + ((long)tile * ns + s) * ((long)L::PJ * G.rs)) + la;
+        const double2 *ch = reinterpret_cast<const double2 *>(Jt + ((long)tile * ns + s) * ((long)L::PJ * RS)) + la;
         double v[2 * L::PJ];
 #pragma unroll
         for (int p = 0; p < L::PJ; ++p) {
-            const double2 t = ch[p * G.nl];
+            const double2 t = ch[p * NL];
             v[2 * p] = t.x;
             v[2 * p + 1] = t.y;
         }
@@ -215,8 +220,8 @@ __global__ __launch_bounds__(64) void k_ilu_factor(IluGeom G, const double *__re
                 Amc[2][r][q] = __shfl_up(Aprev[2][r][q], G.t1, 64);
             }
         double D[B][B], Di[B][B];
-        double *fch = fwd + ((long)tile * ns + s) * ((long)L::PF * G.rs);
-        double *bch = bwd + ((long)tile * ns + s) * ((long)L::PB * G.rs);
+        double *fch = fwd + ((long)tile * ns + s) * ((long)L::PF * RS);
+        double *bch = bwd + ((long)tile * ns + s) * ((long)L::PB * RS);
 #pragma unroll
         for (int r = 0; r < B; ++r)
 #pragma unroll
@@ -242,10 +247,10 @@ __global__ __launch_bounds__(64) void k_ilu_factor(IluGeom G, const double *__re
                     for (int t = 0; t < B; ++t) v += Bm[r][t] * Amc[a][t][q];
                     D[r][q] -= v;
                     const int e = (a * B + r) * B + q;
-                    if (live) fch[(e >> 1) * G.rs + lane * 2 + (e & 1)] = Bm[r][q];
+                    if (live) fch[(e >> 1) * RS + lane * 2 + (e & 1)] = Bm[r][q];
                 }
         }
-        if ((L::NEF & 1) && live) fch[(L::NEF >> 1) * G.rs + lane * 2 + 1] = 0.0;    // padding half of the last pair
+        if ((L::NEF & 1) && live) fch[(L::NEF >> 1) * RS + lane * 2 + 1] = 0.0;    // padding half of the last pair
         if (k.ok) {
             inv_block<B>(D, Di);
         } else {
@@ -265,14 +270,14 @@ __global__ __launch_bounds__(64) void k_ilu_factor(IluGeom G, const double *__re
 #pragma unroll
                     for (int t = 0; t < B; ++t) v += Di[r][t] * k.Aup[a][t][q];
                     const int e = (a * B + r) * B + q;
-                    if (live) bch[(e >> 1) * G.rs + lane * 2 + (e & 1)] = v;
+                    if (live) bch[(e >> 1) * RS + lane * 2 + (e & 1)] = v;
                 }
 #pragma unroll
         for (int r = 0; r < B; ++r)
 #pragma unroll
             for (int q = 0; q < B; ++q) {
                 const int e = (3 * B + r) * B + q;
-                if (live) bch[(e >> 1) * G.rs + lane * 2 + (e & 1)] = Di[r][q];
+                if (live) bch[(e >> 1) * RS + lane * 2 + (e & 1)] = Di[r][q];
                 Dp[r][q] = Di[r][q];
             }
 #pragma unroll
@@ -311,7 +316,7 @@ __device__ __forceinline__ double chunk_get(const double2 (&v)[NP], int e) {
 // step s+3 -- a single wave per CU keeps ~40 KB of HBM reads outstanding.
 // YLDS: the intermediate vector y of the tile (nsteps x B x 64 doubles, 147 KB on C4) stays in the CU's LDS between
 // the two sweeps instead of going through HBM (a write, a read and their row padding: 10 % of the kernel's traffic).
-template <int B, bool DEPTH2, bool YLDS>
+template <int B, bool DEPTH2, bool YLDS, bool CP>
 __global__ __launch_bounds__(64) void k_ilu_solve(IluGeom G, const double *__restrict__ fwd,
                                                   const double *__restrict__ bwd, const double *__restrict__ rhs,
                                                   double *__restrict__ ytmp, double *x, const double *addto,
@@ -319,13 +324,15 @@ __global__ __launch_bounds__(64) void k_ilu_solve(IluGeom G, const double *__res
     using L = IluLayout<B>;
     extern __shared__ double ylds[];       // [step][field][lane] when YLDS
     const int tile = blockIdx.x, lane = threadIdx.x;
-    const int la = lane < G.nl ? lane : G.nl - 1;      // idle lanes (>= t1*t2) shadow a live lane's loads
-    const bool live = lane < G.nl;
+    const int NL = CP ? G.nl : 64, RS = CP ? G.rs : 128;
+    const int la = CP ? (lane < NL ? lane : NL - 1) : lane;      // idle lanes (>= t1*t2) shadow a live lane's loads
+    const bool live = CP ? lane < NL : true;                     // (compile-time true with wave-wide rows: see k_ilu_factor)
     const long nt = G.g.ntot;
     const TileInfo ti = tile_info(G, tile, lane);
     const long chunk0 = (long)tile * G.nsteps;
     const int ns = G.nsteps;
-    const long rowF = (long)L::PF * G.rs, rowB = (long)L::PB * G.rs, rowY = (long)L::PY * G.rs;
+    const long rowF = (long)L::PF * RS, rowB = (long)L::PB * RS, rowY = (long)L::PY * RS;
+    const long park = min((long)lane, G.g.np - 1);     // an entry of the lower halo plane: where cell-less lanes read / write
     constexpr int RING = DEPTH2 ? 3 : 2;
     int l0;
     long c;
@@ -339,9 +346,13 @@ __global__ __launch_bounds__(64) void k_ilu_solve(IluGeom G, const double *__res
         bool okk[RING];
         auto load = [&](int k, int step) {
             okk[k] = tile_cell(G, ti, step, l0, c);
-            load_chunk<L::PF>(fwd + (chunk0 + step) * rowF, la, G.nl, buf[k]);
+            load_chunk<L::PF>(fwd + (chunk0 + step) * rowF, la, NL, buf[k]);
+            // BRANCH-FREE: a lane without a cell at this step reads entry `lane` of the lower halo plane (valid memory,
+            // finite) and the value is dropped by a select.  A load or store behind a divergent branch makes the compiler
+            // drain every outstanding load (s_waitcnt vmcnt(0)) at each step, prefetch ring included.
+            const long cs = okk[k] ? c : park;
 #pragma unroll
-            for (int r = 0; r < B; ++r) rr[k][r] = okk[k] ? rhs[(long)r * nt + c] : 0.0;
+            for (int r = 0; r < B; ++r) rr[k][r] = rhs[(long)r * nt + cs];
         };
         auto step = [&](int k, int s) {
             double yn[3][B], y[B];
@@ -350,7 +361,7 @@ __global__ __launch_bounds__(64) void k_ilu_solve(IluGeom G, const double *__res
                 yn[0][r] = yp[r];
                 yn[1][r] = __shfl_up(yp[r], 1, 64);
                 yn[2][r] = __shfl_up(yp[r], G.t1, 64);
-                y[r] = rr[k][r];
+                y[r] = okk[k] ? rr[k][r] : 0.0;
             }
             // B_cm is stored as zero where the neighbour is outside the tile, so no branches here
 #pragma unroll
@@ -360,18 +371,27 @@ __global__ __launch_bounds__(64) void k_ilu_solve(IluGeom G, const double *__res
 #pragma unroll
                     for (int q = 0; q < B; ++q) y[r] -= chunk_get<L::PF>(buf[k], (a * B + r) * B + q) * yn[a][q];
             double *ych = ytmp + (chunk0 + s) * rowY;
+            const long ydump = ((long)G.nsteps * gridDim.x - (chunk0 + s)) * rowY + ((long)tile * 64 + lane) * B;
 #pragma unroll
             for (int r = 0; r < B; ++r) {
                 y[r] = okk[k] ? y[r] : 0.0;
                 if (YLDS) ylds[((long)s * B + r) * 64 + lane] = y[r];
-                else if (live) ych[(r >> 1) * G.rs + lane * 2 + (r & 1)] = y[r];
+                else ych[live ? (long)(r >> 1) * RS + lane * 2 + (r & 1) : ydump + r] = y[r];      // (idle lanes: parking slot)
                 yp[r] = y[r];
             }
         };
 #pragma unroll
         for (int k = 0; k < RING; ++k)
             if (k < ns) load(k, k);
-        for (int s = 0; s < ns; s += RING) {
+        int s = 0;
+        for (; s + 2 * RING <= ns; s += RING) {          // steady state: no condition inside the body
+#pragma unroll
+            for (int k = 0; k < RING; ++k) {
+                step(k, s + k);
+                load(k, s + k + RING);
+            }
+        }
+        for (; s < ns; s += RING) {
 #pragma unroll
             for (int k = 0; k < RING; ++k) {
                 if (s + k < ns) {
@@ -390,14 +410,23 @@ __global__ __launch_bounds__(64) void k_ilu_solve(IluGeom G, const double *__res
         double aa[RING][B];
         bool okk[RING];
         long cc[RING];
+        // fields >= nadd of addto count as zero: read a valid array instead and multiply by a 0/1 mask (no branch)
+        const double *asrc[B];
+        double amask[B];
+#pragma unroll
+        for (int r = 0; r < B; ++r) {
+            const bool use = addto && r < nadd;
+            asrc[r] = (use ? addto : rhs) + (long)r * nt;
+            amask[r] = use ? 1.0 : 0.0;
+        }
         auto load = [&](int k, int step) {
             okk[k] = tile_cell(G, ti, step, l0, c);
             cc[k] = c;
-            load_chunk<L::PB>(bwd + (chunk0 + step) * rowB, la, G.nl, buf[k]);
-            if (!YLDS) load_chunk<(YLDS ? 1 : L::PY)>(ytmp + (chunk0 + step) * rowY, la, G.nl, ybuf[k]);
+            load_chunk<L::PB>(bwd + (chunk0 + step) * rowB, la, NL, buf[k]);
+            if (!YLDS) load_chunk<(YLDS ? 1 : L::PY)>(ytmp + (chunk0 + step) * rowY, la, NL, ybuf[k]);
+            const long cs = okk[k] ? c : park;                // branch-free, as in the forward sweep
 #pragma unroll
-            for (int r = 0; r < B; ++r)      // fields >= nadd of addto are taken as zero (never read)
-                aa[k][r] = (okk[k] && addto && r < nadd) ? addto[(long)r * nt + c] : 0.0;
+            for (int r = 0; r < B; ++r) aa[k][r] = asrc[r][cs];
         };
         auto step = [&](int k, int s) {
             double xn[3][B], xv[B], yv[B];
@@ -425,7 +454,9 @@ __global__ __launch_bounds__(64) void k_ilu_solve(IluGeom G, const double *__res
             for (int r = 0; r < B; ++r) {
                 xv[r] = okk[k] ? xv[r] : 0.0;
                 xp[r] = xv[r];
-                if (okk[k]) x[(long)r * nt + cc[k]] = aa[k][r] + xv[r];
+                // unconditional store: lanes without a cell write 0.0 to entry `lane` of x's lower halo plane (never read
+                // with a non-zero coefficient on one GPU, overwritten by the next halo exchange on several)
+                x[(long)r * nt + (okk[k] ? cc[k] : park)] = okk[k] ? amask[r] * aa[k][r] + xv[r] : 0.0;
             }
         };
         // the forward sweep's y of the last steps may still be in flight as stores: same-lane same-address
@@ -433,7 +464,15 @@ __global__ __launch_bounds__(64) void k_ilu_solve(IluGeom G, const double *__res
 #pragma unroll
         for (int k = 0; k < RING; ++k)
             if (ns - 1 - k >= 0) load(k, ns - 1 - k);
-        for (int s = ns - 1; s >= 0; s -= RING) {
+        int s = ns - 1;
+        for (; s - 2 * RING + 1 >= 0; s -= RING) {       // steady state: no condition inside the body
+#pragma unroll
+            for (int k = 0; k < RING; ++k) {
+                step(k, s - k);
+                load(k, s - k - RING);
+            }
+        }
+        for (; s >= 0; s -= RING) {
 #pragma unroll
             for (int k = 0; k < RING; ++k) {
                 if (s - k >= 0) {
@@ -445,6 +484,12 @@ __global__ __launch_bounds__(64) void k_ilu_solve(IluGeom G, const double *__res
     }
 }
 
+// Rows as wide as the tile (t1*t2 double2) or as wide as the wave (64).  Compact rows save the padding bytes of tiles
+// that do not fill a wave -- what the bandwidth-bound 3-D sweeps need -- but make the row stride a run-time value: the
+// 14-18 loads of a step then need scalar address arithmetic instead of immediate offsets, and the small 2-D
+// configurations, which are bound by the single wave's instruction issue, lose 15-25 % (C1: 0.24 -> 0.28 ms).
+static bool ilu_compact(const tp_ctx *c) { return c->g.gn2 > 1 && c->ilu.t1 * c->ilu.t2 < 64; }
+
 static IluGeom geom_of(const tp_ctx *c) {
     IluGeom G;
     G.g = c->g;
@@ -452,17 +497,17 @@ static IluGeom geom_of(const tp_ctx *c) {
     G.nt0 = c->ilu.nt0; G.nt1 = c->ilu.nt1; G.nt2 = c->ilu.nt2;
     G.nsteps = c->ilu.nsteps;
     G.nl = G.t1 * G.t2;
-    G.rs = 2 * G.nl;
+    G.rs = ilu_compact(c) ? 2 * G.nl : 128;
     return G;
 }
 
 template <int B>
-static void alloc_factor(IluData &d) {
+static void alloc_factor(IluData &d, bool compact) {
     using L = IluLayout<B>;
-    const size_t chunks = (size_t)d.ntiles * d.nsteps, rs = (size_t)2 * d.t1 * d.t2;      // rows as wide as the tile
+    const size_t chunks = (size_t)d.ntiles * d.nsteps, rs = compact ? (size_t)2 * d.t1 * d.t2 : 128;
     d.fwd.alloc(chunks * L::PF * rs);
     d.bwd.alloc(chunks * L::PB * rs);
-    d.ytmp.alloc(chunks * L::PY * rs);
+    d.ytmp.alloc(chunks * L::PY * rs + (size_t)d.ntiles * 64 * B);     // + parking slots of idle lanes (branch-free stores)
     d.jt.alloc(chunks * L::PJ * rs);
 }
 
@@ -486,7 +531,7 @@ void ilu_setup(tp_ctx *c) {
     d.nsteps = t0 + t1 + t2 - 2;
     d.slots = (long)d.ntiles * d.nsteps * 64;
     c->graph_epoch++;            // new tile layout / factor buffers: captured pc_apply graphs are stale
-    if (c->b == 3) alloc_factor<3>(d); else alloc_factor<2>(d);
+    if (c->b == 3) alloc_factor<3>(d, ilu_compact(c)); else alloc_factor<2>(d, ilu_compact(c));
 }
 
 void ilu_factor(tp_ctx *c) {
@@ -494,18 +539,36 @@ void ilu_factor(tp_ctx *c) {
     if (c->ilu.slots == 0) ilu_setup(c);
     const IluGeom G = geom_of(c);
     const int nseg = (G.nsteps + ILU_SEG - 1) / ILU_SEG;
-    if (c->b == 3) {
-        hipLaunchKernelGGL(k_ilu_gather<3>, dim3(c->ilu.ntiles, (IluLayout<3>::PJ + ILU_PPT - 1) / ILU_PPT, nseg), dim3(64 * ILU_SEG), 0, c->stream, G,
-                           c->J.p, c->ilu.jt.p);
-        hipLaunchKernelGGL(k_ilu_factor<3>, dim3(c->ilu.ntiles), dim3(64), 0, c->stream, G, c->ilu.jt.p, c->ilu.fwd.p,
-                           c->ilu.bwd.p);
-    } else {
-        hipLaunchKernelGGL(k_ilu_gather<2>, dim3(c->ilu.ntiles, (IluLayout<2>::PJ + ILU_PPT - 1) / ILU_PPT, nseg), dim3(64 * ILU_SEG), 0, c->stream, G,
-                           c->J.p, c->ilu.jt.p);
-        hipLaunchKernelGGL(k_ilu_factor<2>, dim3(c->ilu.ntiles), dim3(64), 0, c->stream, G, c->ilu.jt.p, c->ilu.fwd.p,
-                           c->ilu.bwd.p);
-    }
+    const bool cp = ilu_compact(c);
+#define TP_ILU_FACTOR(BB, CC)                                                                                          \
+    do {                                                                                                               \
+        hipLaunchKernelGGL((k_ilu_gather<BB, CC>), dim3(c->ilu.ntiles, (IluLayout<BB>::PJ + ILU_PPT - 1) / ILU_PPT, nseg), \
+                           dim3(64 * ILU_SEG), 0, c->stream, G, c->J.p, c->ilu.jt.p);                                   \
+        hipLaunchKernelGGL((k_ilu_factor<BB, CC>), dim3(c->ilu.ntiles), dim3(64), 0, c->stream, G, c->ilu.jt.p,        \
+                           c->ilu.fwd.p, c->ilu.bwd.p);                                                                \
+    } while (0)
+    if (c->b == 3) { if (cp) TP_ILU_FACTOR(3, true); else TP_ILU_FACTOR(3, false); }
+    else           { if (cp) TP_ILU_FACTOR(2, true); else TP_ILU_FACTOR(2, false); }
+#undef TP_ILU_FACTOR
     TP_HIP(hipGetLastError());
+}
+
+template <int BB, bool DD, bool CC>
+static void ilu_solve_launch(tp_ctx *c, const IluGeom &G, bool ylds, size_t ybytes, const double *r, double *x,
+                             const double *addto, int nadd) {
+    if (ylds) {
+        static bool attr_set = false;        // (one flag per instantiation)
+        if (!attr_set) {
+            TP_HIP(hipFuncSetAttribute(reinterpret_cast<const void *>(&k_ilu_solve<BB, DD, true, CC>),
+                                       hipFuncAttributeMaxDynamicSharedMemorySize, 152 * 1024));
+            attr_set = true;
+        }
+        hipLaunchKernelGGL((k_ilu_solve<BB, DD, true, CC>), dim3(c->ilu.ntiles), dim3(64), ybytes, c->stream, G, c->ilu.fwd.p,
+                           c->ilu.bwd.p, r, c->ilu.ytmp.p, x, addto, nadd);
+    } else {
+        hipLaunchKernelGGL((k_ilu_solve<BB, DD, false, CC>), dim3(c->ilu.ntiles), dim3(64), 0, c->stream, G, c->ilu.fwd.p,
+                           c->ilu.bwd.p, r, c->ilu.ytmp.p, x, addto, nadd);
+    }
 }
 
 void ilu_solve(tp_ctx *c, const double *r, double *x, const double *addto, int nadd) {
@@ -517,26 +580,16 @@ void ilu_solve(tp_ctx *c, const double *r, double *x, const double *addto, int n
     // y in LDS when the tile's whole intermediate vector fits one CU's 160 KB (one workgroup per CU then)
     const size_t ybytes = (size_t)G.nsteps * c->b * 64 * sizeof(double);
     const bool ylds = ylds_on && ybytes <= 152 * 1024;
-    static bool attr_set = false;
-    if (ylds && !attr_set) {
-        const int lim = 152 * 1024;
-        TP_HIP(hipFuncSetAttribute(reinterpret_cast<const void *>(&k_ilu_solve<3, true, true>), hipFuncAttributeMaxDynamicSharedMemorySize, lim));
-        TP_HIP(hipFuncSetAttribute(reinterpret_cast<const void *>(&k_ilu_solve<3, false, true>), hipFuncAttributeMaxDynamicSharedMemorySize, lim));
-        TP_HIP(hipFuncSetAttribute(reinterpret_cast<const void *>(&k_ilu_solve<2, true, true>), hipFuncAttributeMaxDynamicSharedMemorySize, lim));
-        TP_HIP(hipFuncSetAttribute(reinterpret_cast<const void *>(&k_ilu_solve<2, false, true>), hipFuncAttributeMaxDynamicSharedMemorySize, lim));
-        attr_set = true;
-    }
-#define TP_ILU_LAUNCH(BB, DD, YY)                                                                                     \
-    hipLaunchKernelGGL((k_ilu_solve<BB, DD, YY>), dim3(c->ilu.ntiles), dim3(64), (YY) ? ybytes : 0, c->stream, G,     \
-                       c->ilu.fwd.p, c->ilu.bwd.p, r, c->ilu.ytmp.p, x, addto, nadd)
+    const bool cp = ilu_compact(c);
 #define TP_ILU_PICK(BB)                                                                                               \
     do {                                                                                                              \
-        if (deep) { if (ylds) TP_ILU_LAUNCH(BB, true, true); else TP_ILU_LAUNCH(BB, true, false); }                   \
-        else      { if (ylds) TP_ILU_LAUNCH(BB, false, true); else TP_ILU_LAUNCH(BB, false, false); }                 \
+        if (deep) { if (cp) ilu_solve_launch<BB, true, true>(c, G, ylds, ybytes, r, x, addto, nadd);                  \
+                    else ilu_solve_launch<BB, true, false>(c, G, ylds, ybytes, r, x, addto, nadd); }                  \
+        else      { if (cp) ilu_solve_launch<BB, false, true>(c, G, ylds, ybytes, r, x, addto, nadd);                 \
+                    else ilu_solve_launch<BB, false, false>(c, G, ylds, ybytes, r, x, addto, nadd); }                 \
     } while (0)
     if (c->b == 3) TP_ILU_PICK(3); else TP_ILU_PICK(2);
 #undef TP_ILU_PICK
-#undef TP_ILU_LAUNCH
     TP_HIP(hipGetLastError());
 }
 
