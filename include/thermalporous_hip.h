@@ -93,6 +93,11 @@ typedef struct tp_options {
     int32_t amg_gather_cells;/* multi-GPU: AMG levels with more cells than this stay distributed over the slabs
                                 (halo exchange per sweep); smaller ones are gathered and replicated on every
                                 rank.  < 0: replicate the whole hierarchy.  Ignored on one GPU. */
+    double  amg_dom_tau;     /* relaxation-only truncation: the first V(nu,nu) level whose operator has
+                                max_i sum_{j!=i}|a_ij| / |a_ii| <= amg_dom_tau ends the cycle with two damped-Jacobi
+                                sweeps (no coarse-grid correction: damped Jacobi already contracts by
+                                1 - omega (1 - tau) per sweep there; BoomerAMG's max_row_sum rule for diagonally dominant
+                                rows).  Hits the temperature operator S~ of pc_cptr, never the pressure.  0: off. */
 } tp_options;
 
 /* Result of one nonlinear solve (SNES iteration number / linear iterations / reason:
@@ -199,6 +204,9 @@ int tp_newton_solve(tp_ctx *ctx, tp_solve_info *info);
  * step against 16 basis vectors (VecMDot + VecMAXPY + VecNorm; needs a Krylov basis from an earlier solve). */
 int tp_time_kernel(tp_ctx *ctx, int32_t which, int32_t reps, double *ms_avg);
 int tp_amg_info(tp_ctx *ctx, int32_t which, int32_t *nlevels, double *op_complexity);
+/* level at which hierarchy `which` ends with relaxation only (amg_dom_tau), -1: full V-cycle; ratio0 = the
+ * dominance ratio measured on level 0 at the last set-up */
+int tp_amg_trunc(tp_ctx *ctx, int32_t which, int32_t *level, double *ratio0);
 /* coarsening axis of every level (internal axis numbering, 2 = slab axis) and how many of the top levels are
  * distributed over the slabs (0 on one GPU and when the hierarchy is replicated, see amg_gather_cells) */
 int tp_amg_layout(tp_ctx *ctx, int32_t which, int32_t *dist_levels, int32_t *axes, int32_t cap, int32_t *naxes);

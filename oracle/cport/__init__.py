@@ -29,7 +29,7 @@ class _Opts(C.Structure):
                 ("amg_omega", C.c_double), ("amg_nu", C.c_int32), ("amg_min_cells", C.c_int32),
                 ("amg_full_levels", C.c_int32), ("amg_coarse_pre", C.c_int32), ("amg_coarse_post", C.c_int32),
                 ("amg_mid_skip", C.c_int32), ("amg_tail_post", C.c_int32), ("amg_single", C.c_int32),
-                ("schur_a11", C.c_int32), ("tile", C.c_int32*3), ("nslabs", C.c_int32)]
+                ("schur_a11", C.c_int32), ("tile", C.c_int32*3), ("nslabs", C.c_int32), ("amg_dom_tau", C.c_double)]
 
 
 class _Info(C.Structure):
@@ -56,6 +56,7 @@ def load():
         lib.cp_fgmres.restype = C.c_int
         lib.cp_amg_levels.restype = C.c_int
         lib.cp_ntiles.restype = C.c_int
+        lib.cp_amg_trunc.restype = C.c_int
         _LIB = lib
     return _LIB
 
@@ -116,7 +117,7 @@ class CPortEngine:
                         o["amg_min_cells"], int(o.get("amg_full_levels", 99)), neg(o.get("amg_coarse_pre")),
                         neg(o.get("amg_coarse_post")), int(bool(o.get("amg_mid_skip", False))), neg(o.get("amg_tail_post")),
                         int(bool(o.get("amg_single", False))), int(bool(o.get("schur_a11", False))), (C.c_int32*3)(*t),
-                        int(o.get("nslabs", 1)))
+                        int(o.get("nslabs", 1)), float(o.get("amg_dom_tau", 0.0)))
         prm = np.array([float(spec["prm"][k]) for k in _PRM])
         kT = spec.get("kT")
         self.ctx = C.c_void_p(self.lib.cp_create(
@@ -224,6 +225,10 @@ class CPortEngine:
 
     def amg_levels(self, which=0):
         return self.lib.cp_amg_levels(self.ctx, which)
+
+    def amg_trunc(self, which=0):
+        """Level at which hierarchy `which` ends with relaxation only (amg_dom_tau), -1: full V-cycle."""
+        return self.lib.cp_amg_trunc(self.ctx, which)
 
     def ntiles(self):
         return self.lib.cp_ntiles(self.ctx)

@@ -97,6 +97,7 @@ struct Opts {
         amg_single, schur_a11;
     int32_t tile[3];
     int32_t nslabs;
+    double amg_dom_tau;
 };
 
 struct Info {
@@ -172,6 +173,8 @@ struct SemiAMG {
     int nu = 1, full_levels = 99, coarse_pre = 1, coarse_post = 1, tail_post = 1;
     bool mid_skip = false, single = false;
     vec coarseLU;
+    int trunc_level = -1;      // first strongly diagonally dominant V(nu,nu) level (relaxation only), -1: none
+    double dom_tau = 0.0;
     std::vector<int> piv;
     int ncoarse = 0;
     std::vector<vec> wx, wr, wb, we, wt;       // per-level work vectors
@@ -185,6 +188,7 @@ struct SemiAMG {
         tail_post = o.amg_tail_post < 0 ? coarse_post : o.amg_tail_post;
         mid_skip = o.amg_mid_skip != 0;
         single = o.amg_single != 0;
+        dom_tau = o.amg_dom_tau;
         int n[3] = {n_[0], n_[1], n_[2]};
         double s[3];
         for (int a = 0; a < 3; ++a) s[a] = n[a] > 1 ? strength[a] : -1.0;
@@ -277,6 +281,21 @@ struct SemiAMG {
         for (auto &L : lv) {
 #pragma omp parallel for schedule(static)
             for (long c = 0; c < L.g.N; ++c) L.invd(c) = store(omega / L.A(0, c));
+        }
+        trunc_level = -1;
+        if (dom_tau > 0.0) {
+            const int lim = std::min(full_levels, (int)lv.size() - 1);
+            for (int l = 0; l < lim; ++l) {
+                const AmgLevel &L = lv[l];
+                double mx = 0.0;
+#pragma omp parallel for reduction(max : mx) schedule(static)
+                for (long c = 0; c < L.g.N; ++c) {
+                    double so = 0.0;
+                    for (int s = 1; s < 7; ++s) so += std::fabs(L.A(s, c));
+                    mx = std::max(mx, so / std::fabs(L.A(0, c)));
+                }
+                if (mx <= dom_tau) { trunc_level = l; break; }
+            }
         }
         // coarsest grid: dense LU with partial pivoting (the oracle uses SuperLU on the same <= min_cells matrix)
         AmgLevel &Lc = lv.back();
@@ -381,6 +400,15 @@ struct SemiAMG {
     void vcycle(const double *b, double *x, int l = 0) {
         AmgLevel &L = lv[l];
         const long N = L.g.N;
+        if (trunc_level >= 0 && l == trunc_level) {      // relaxation-only level (SemiAMG dom_tau): two damped-Jacobi sweeps
+            double *t = wt[l].data(), *x2 = wx[l].data();
+#pragma omp parallel for schedule(static)
+            for (long c = 0; c < N; ++c) x[c] = L.invd(c) * b[c];
+            smooth(l, b, x, x2, t);
+#pragma omp parallel for schedule(static)
+            for (long c = 0; c < N; ++c) x[c] = x2[c];
+            return;
+        }
         if (l == (int)lv.size() - 1) {
             if (N == 1) { x[0] = b[0] / L.A(0, 0); return; }
             coarse_solve(b, x);
@@ -1348,7 +1376,9 @@ void *cp_create(int nphase, const int *n, const double *h, int gaxis, const doub
         sg[a] = C->g.n[a] > 1 ? C->G[a] : 0.0;
     }
     C->amg_p.init(C->g.n, st, C->o);
-    if (C->o.pc >= 1) C->amg_T.init(C->g.n, sg, C->o);
+    if (C->o.pc >= 1) {
+        C->amg_T.init(C->g.n, sg, C->o);
+    }
     return C;
 }
 
@@ -1422,6 +1452,7 @@ long cp_amg_level(void *c, int which, int l, double *A, double *w, double *invd)
     if (w && L.axis >= 0) { std::copy(L.wm.begin(), L.wm.end(), w); std::copy(L.wp.begin(), L.wp.end(), w + L.g.N); }
     return L.g.N;
 }
+int cp_amg_trunc(void *c, int which) { Ctx *C = (Ctx *)c; return (which == 0 ? C->amg_p : C->amg_T).trunc_level; }
 int cp_ntiles(void *c) { Ctx *C = (Ctx *)c; if (C->tiles.empty()) ilu_layout(*C); return (int)C->tiles.size(); }
 
 }  // extern "C"

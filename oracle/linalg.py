@@ -185,7 +185,7 @@ class SemiAMG:
     """
 
     def __init__(self, n, strength, omega=0.8, min_cells=64, nu=1, max_levels=40, full_levels=99, coarse_pre=None,
-                 coarse_post=None, single=False, tail_post=None, mid_skip=False):
+                 coarse_post=None, single=False, tail_post=None, mid_skip=False, dom_tau=0.0):
         """V(nu,nu) on the first `full_levels` levels, V(coarse_pre, coarse_post) below (the coarse levels of
         the GPU cycle are launch-latency bound: dropping their pre-smoothing costs no Krylov iterations)."""
         self.n = tuple(n)
@@ -198,6 +198,15 @@ class SemiAMG:
         self.tail_post = self.coarse_post if tail_post is None else tail_post
         # every second level between the full ones and the <= 1024-cell ones is a pure transfer level
         self.mid_skip = bool(mid_skip)
+        # Relaxation-only truncation: the first of the V(nu,nu) levels whose operator is strongly diagonally dominant in
+        # every row (max_i sum_{j != i} |a_ij| / |a_ii| <= dom_tau) ends the cycle with two damped-Jacobi sweeps from a
+        # zero guess -- damped Jacobi contracts the error there by <= 1 - omega (1 - dom_tau) per sweep, so a coarse-grid
+        # correction has nothing left to do.  (BoomerAMG's own rule for such rows, -pc_hypre_boomeramg_max_row_sum 0.9:
+        # rows dominated by their diagonal have no strong connections and are not coarsened.)  This is the temperature
+        # operator S~ of pc_cptr at every time step of the BASELINE configurations (ratio 0.03-0.14); the pressure
+        # operator has ratio 1 and is never truncated.  0 disables.
+        self.dom_tau = float(dom_tau)
+        self.trunc = None
         self.sched = self._schedule(n, strength, min_cells, max_levels)
 
     @staticmethod
@@ -267,6 +276,13 @@ class SemiAMG:
             self.levels.append(self._store(Ac))
             self.W.append(w)
         self.invd = [self._store(self.omega / l[0]) for l in self.levels]
+        self.trunc = None
+        if self.dom_tau > 0.0:
+            for l in range(min(self.full_levels, len(self.levels) - 1)):
+                A_l = self.levels[l]
+                if float((np.abs(A_l[1:]).sum(axis=0) / np.abs(A_l[0])).max()) <= self.dom_tau:
+                    self.trunc = l
+                    break
         import scipy.sparse.linalg as spla
         M = to_csr(self.levels[-1][:, None, None])
         self.coarse = spla.splu(M.tocsc()) if M.shape[0] > 1 else None
@@ -311,6 +327,8 @@ class SemiAMG:
 
     def vcycle(self, b, lvl=0):
         A = self.levels[lvl]
+        if self.trunc is not None and lvl == self.trunc:      # relaxation-only level (see dom_tau)
+            return self._smooth(lvl, b, self.invd[lvl] * b)
         if lvl == len(self.levels) - 1:
             if self.coarse is None:
                 return b / self.coarse_scalar
@@ -346,6 +364,7 @@ class BlockSemiAMG(SemiAMG):
       * smoother: damped block-Jacobi with the nb x nb diagonal blocks; dense solve on the coarsest grid."""
 
     def __init__(self, n, strength, nb=2, **kw):
+        kw = dict(kw, dom_tau=0.0)            # the (p,T) system contains the pressure rows: never relaxation-only
         super().__init__(n, strength, **kw)
         self.nb = nb
 
@@ -542,7 +561,8 @@ class TwoStagePC:
         kw = dict(omega=opts["amg_omega"], min_cells=opts["amg_min_cells"], nu=opts["amg_nu"],
                   full_levels=opts.get("amg_full_levels", 99), coarse_pre=opts.get("amg_coarse_pre"),
                   coarse_post=opts.get("amg_coarse_post"), single=opts.get("amg_single", False),
-                  tail_post=opts.get("amg_tail_post"), mid_skip=opts.get("amg_mid_skip", False))
+                  tail_post=opts.get("amg_tail_post"), mid_skip=opts.get("amg_mid_skip", False),
+                  dom_tau=opts.get("amg_dom_tau", 0.0))
 
         # coarsening schedule from the mean interior-face transmissibility per axis
         st = [float(np.mean(prob.TK[a][_lo(a)])) if n[a] > 1 else 0.0 for a in range(3)]

@@ -22,11 +22,11 @@ import cases                                    # noqa: E402
 from oracle.engine import OracleEngine          # noqa: E402
 
 CASES = {
-    "c1_1ph_2d": (cases.c1_homogeneous, dict(N=8, nphase=1), dict(pc="cpr", ilu_tile=(1 << 30, 64, 1)), 86400.0),
+    "c1_1ph_2d": (cases.c1_homogeneous, dict(N=8, nphase=1), dict(pc="cpr", ilu_tile=(1 << 30, 64, 1), amg_dom_tau=0.0), 86400.0),
     "c3_2ph_2d": (cases.c3_spe10_2d, dict(Nx=10, Ny=12, nphase=2),
-                  dict(pc="cptr", ksp_rtol=1e-8, snes_max_it=25, ilu_tile=(1 << 30, 64, 1)), 864.0),
-    "c4_2ph_3d": (cases.c4_spe10_3d, dict(Nx=6, Ny=7, Nz=5, nphase=2), dict(pc="cptr", ksp_rtol=1e-8, snes_max_it=25, ilu_tile=(1 << 30, 8, 8)), 86.4),   # (tile pinned: the fixture predates the balanced default)
-    "c4_1ph_3d_fscd": (cases.c4_spe10_3d, dict(Nx=6, Ny=7, Nz=5, nphase=1), dict(pc="fieldsplit_cd", ksp_rtol=1e-8), 864.0),
+                  dict(pc="cptr", ksp_rtol=1e-8, snes_max_it=25, ilu_tile=(1 << 30, 64, 1), amg_dom_tau=0.0), 864.0),
+    "c4_2ph_3d": (cases.c4_spe10_3d, dict(Nx=6, Ny=7, Nz=5, nphase=2), dict(pc="cptr", ksp_rtol=1e-8, snes_max_it=25, ilu_tile=(1 << 30, 8, 8), amg_dom_tau=0.0), 86.4),   # (tile and amg_dom_tau pinned: the fixtures predate the balanced tile and the relaxation-only truncation)
+    "c4_1ph_3d_fscd": (cases.c4_spe10_3d, dict(Nx=6, Ny=7, Nz=5, nphase=1), dict(pc="fieldsplit_cd", ksp_rtol=1e-8, amg_dom_tau=0.0), 864.0),
 }
 
 

@@ -149,6 +149,9 @@ def test_linear_stages_parity(name, builder, kw, opts):
         vtol = 1e-6      # column sums cancel to ~1e-9 of their terms and pass through a 2x2 inverse: summation order shows
     assert rel2(h.vec_get("y")[0], o.pc.amg_p.vcycle(x[0])) < vtol
     if schur:
+        # same relaxation-only truncation decision (amg_dom_tau) on both sides
+        assert h.amg_trunc(1)[0] == (-1 if o.pc.amg_T.trunc is None else o.pc.amg_T.trunc)
+        assert h.amg_trunc(0)[0] == (-1 if o.pc.amg_p.trunc is None else o.pc.amg_p.trunc)
         h.amg_vcycle(1, "x", 1, "y", 1)
         assert rel2(h.vec_get("y")[1], o.pc.amg_T.vcycle(x[1])) < vtol
     h.stage1_apply("x", "y")
@@ -250,4 +253,48 @@ def test_ksp_residual_monitor_per_field():
     n0 = len(seen)
     h.fgmres("b", "d")                      # monitor removed: no more calls
     assert len(seen) == n0
+    h.close()
+
+
+@pytest.mark.parametrize("grid,dt,expect", [((7, 13, 9), 86.4, 0), ((20, 26, 18), 86.4, 0), ((20, 26, 18), 4.0e6, -1),
+                                            ((20, 26, 18), 86.4, None)],
+                         ids=["tail_truncated", "big_truncated", "not_dominant", "tau_off"])
+def test_dominance_truncated_hierarchy(grid, dt, expect):
+    """amg_dom_tau: at small dt the temperature operator S~ is strongly diagonally dominant and its hierarchy ends on
+    level 0 with two Jacobi sweeps (inside the single-workgroup tail on the small grid, as a streaming kernel on the
+    larger one); at a huge dt it is not and the full V-cycle runs; the pressure hierarchy is never truncated.  GPU and
+    oracle take the same decision and agree on every stage."""
+    opts = dict(pc="cptr", ksp_rtol=1e-8)
+    if expect is None:
+        opts["amg_dom_tau"] = 0.0
+    spec, u0, o, h = make(cases.c4_spe10_3d, opts, Nx=grid[0], Ny=grid[1], Nz=grid[2], nphase=2)
+    u = cases.perturbed_state(spec, seed=5, amp=0.05)
+    for e in (o, h):
+        e.set_old(u0)
+        e.set_dt(dt)
+        e.set_state(u)
+    J, Sm = o.jacobian(want_schur=True)
+    h.jacobian()
+    o.pc.setup(J, Sm)
+    h.pc_setup()
+    tT, r0 = h.amg_trunc(1)
+    want = -1 if expect is None else expect
+    assert tT == want == (-1 if o.pc.amg_T.trunc is None else o.pc.amg_T.trunc), (tT, r0, o.pc.amg_T.trunc)
+    assert h.amg_trunc(0)[0] == -1 and o.pc.amg_p.trunc is None
+    if expect is not None:
+        ratio = float((np.abs(Sm[1:]).sum(axis=0)/np.abs(Sm[0])).max())
+        assert abs(r0 - ratio) <= 1e-12*ratio
+    x = np.random.default_rng(11).standard_normal(u.shape)
+    h.vec_set("x", x)
+    h.amg_vcycle(1, "x", 1, "y", 1)
+    assert rel2(h.vec_get("y")[1], o.pc.amg_T.vcycle(x[1])) < 1e-10
+    h.pc_apply("x", "y")
+    assert rel2(h.vec_get("y"), o.pc.apply(x)) < (1e-9 if dt > 1e5 else 1e-10)      # (dt = 46 days: badly conditioned)
+    import oracle.linalg as la
+    F = o.residual()
+    h.residual()
+    h.copy_residual_to("b")
+    its_h, reason_h, _ = h.fgmres("b", "d")
+    d_o, its_o, reason_o, _ = la.fgmres(lambda v: la.spmv_block(J, v), o.pc.apply, F, rtol=1e-8)
+    assert reason_h == reason_o == 2 and abs(its_h - its_o) <= 1
     h.close()

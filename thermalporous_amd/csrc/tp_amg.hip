@@ -62,13 +62,26 @@ __device__ __forceinline__ bool open_hi(const GridDev &g, int a) { return a == 2
 // ---- set-up kernels --------------------------------------------------------------------------------
 // interpolation weights of every cell w.r.t. axis a (only odd cells are used) + invd = omega/diag
 template <class R>
-__global__ void k_amg_weights(GridDev g, StencilT<R> A, int axis, double omega, R *wm, R *wp, R *invd) {
+__global__ void k_amg_weights(GridDev g, StencilT<R> A, int axis, double omega, R *wm, R *wp, R *invd,
+                              unsigned long long *ratio_slots) {
     const long tid = (long)blockIdx.x * blockDim.x + threadIdx.x;
-    if (tid >= g.nown) return;
-    const long c = g.np + tid;
+    const bool in = tid < g.nown;
+    const long c = g.np + (in ? tid : 0);
     const double a0 = A.slot(0)[c];
-    invd[c] = (R)(omega / a0);
-    if (axis < 0) return;
+    if (in) invd[c] = (R)(omega / a0);
+    if (ratio_slots) {
+        // dominance ratio sum_{s>=1}|a_s| / |a_0| of the row, max over the level (tp_options.amg_dom_tau): wave max by
+        // shuffles, then ONE atomic per wave on one of 64 slots (non-negative doubles order like their bit patterns)
+        double so = 0.0;
+#pragma unroll
+        for (int s = 1; s < 7; ++s) so += fabs((double)A.slot(s)[c]);
+        double r = in ? so / fabs(a0) : 0.0;
+#pragma unroll
+        for (int o = 32; o > 0; o >>= 1) r = fmax(r, __shfl_down(r, o, 64));
+        if ((threadIdx.x & 63) == 0)
+            atomicMax(&ratio_slots[(blockIdx.x * (blockDim.x >> 6) + (threadIdx.x >> 6)) & 63], (unsigned long long)__double_as_longlong(r));
+    }
+    if (!in || axis < 0) return;
     double cc = a0;
 #pragma unroll
     for (int s = 1; s < 7; ++s)
@@ -512,9 +525,11 @@ __global__ __launch_bounds__(256) void k_amg_prolong_add(LevelDevT<R> Lf, GridDe
 
 // ---- the tail: all small levels in one workgroup --------------------------------------------------------
 template <class R>
-__global__ __launch_bounds__(1024) void k_amg_tail(const LevelDevT<R> *lv, int l0, int nlev, int nu, int ncoarse,
+__global__ __launch_bounds__(1024) void k_amg_tail(const LevelDevT<R> *lv, int l0, int nlev_all, int trunc, int ncoarse,
                                                    const double *Minv, const double *b_top, double *e_top,
                                                    int lds_doubles) {
+    // trunc >= l0: the hierarchy ends at level `trunc` with two damped-Jacobi sweeps instead of the dense solve
+    const int nlev = trunc >= 0 ? trunc + 1 : nlev_all;
     extern __shared__ double dyn[];          // 4 x lds_doubles: the b, e, x, x2 vectors of every tail level
     const int T = blockDim.x, t = threadIdx.x;
     // level descriptors live in LDS: every phase below starts with LDS reads, not a global round trip
@@ -546,7 +561,6 @@ __global__ __launch_bounds__(1024) void k_amg_tail(const LevelDevT<R> *lv, int l
         __syncthreads();
     }
     lv = reinterpret_cast<const LevelDevT<R> *>(slv_raw);
-    (void)nu;
     // Touch every read-only array of the tail (operators, inverse diagonals, weights, the dense inverse) NOW, all
     // at once: they were written by the set-up long ago and have left the L2; otherwise each of the ~10 phases below
     // starts with its own HBM + TLB round trip (~3 us of a ~4 us phase).
@@ -561,7 +575,8 @@ __global__ __launch_bounds__(1024) void k_amg_tail(const LevelDevT<R> *lv, int l
                 if (L.axis >= 0) sink += (double)L.wm[i] + (double)L.wp[i];
             }
         }
-        for (int i = t; i < ncoarse * ncoarse; i += T) sink += Minv[i];
+        if (trunc < 0)
+            for (int i = t; i < ncoarse * ncoarse; i += T) sink += Minv[i];
         if (sink == 1.2345678e-300) e_top[0] = sink;       // never true: keeps the loads alive
     }
     // down-sweep
@@ -592,6 +607,10 @@ __global__ __launch_bounds__(1024) void k_amg_tail(const LevelDevT<R> *lv, int l
         const LevelDevT<R> Lc = lv[nlev - 1];
         const double *b = (nlev - 1 == l0) ? b_top : Lc.b;
         double *e = (nlev - 1 == l0) ? e_top : Lc.e;
+        if (trunc >= 0) {                 // relaxation-only level: x = x1 + invd (b - A x1), x1 = invd b
+            for (long i = t; i < Lc.g.nown; i += T) e[Lc.g.np + i] = pre2_cell(Lc, b, i);
+            __syncthreads();
+        } else {
         // 16 lanes per row: coalesced reads of the row, 4 independent products per lane, shuffle reduction
         // (one lane per row walked its 64 entries one dependent L2 round trip at a time: ~30 us of a 44 us kernel)
         const int grp = t >> 4, gl = t & 15;
@@ -605,6 +624,7 @@ __global__ __launch_bounds__(1024) void k_amg_tail(const LevelDevT<R> *lv, int l
             if (gl == 0) e[Lc.g.np + r] = s;
         }
         __syncthreads();
+        }
     }
     // up-sweep
     for (int l = nlev - 2; l >= l0; --l) {
@@ -748,6 +768,9 @@ void amg_build(tp_ctx *c, Amg *&amg, const GridDev &g0, const double strength[3]
     }
     amg->ncoarse = (int)amg->lv.back()->g.nown;
     TP_REQUIRE(amg->ncoarse <= 1024, "coarsest AMG grid too large for the dense solve");
+    amg->ratio_dev.alloc(64 * 8);                       // 8 levels x 64 slots is more than amg_full_levels ever needs
+    TP_HIP(hipHostMalloc((void **)&amg->ratio_host, 64 * 8 * sizeof(double)));
+    TP_HIP(hipEventCreateWithFlags(&amg->ev_ratio, hipEventDisableTiming));
     amg->coarse_inv.alloc((size_t)2 * amg->ncoarse * amg->ncoarse);
     // first level handled by the single-workgroup tail kernel
     const long tail_cells = getenv("TP_AMG_TAIL_CELLS") ? atol(getenv("TP_AMG_TAIL_CELLS")) : 1024;
@@ -810,11 +833,16 @@ static void setup_impl(tp_ctx *c, Amg *amg, const Stencil &A0) {
         L0->op.base = L0->A.p;
         L0->op.slot_stride = L0->g.ntot;
     }
+    // relaxation-only truncation: dominance ratios of the V(nu,nu) levels (replicated / single-slab hierarchies only: a
+    // slab-distributed level would need a max-all-reduce of its ratio)
+    const int nratio = (c->opt.amg_dom_tau > 0.0 && lg == 0) ? std::min({c->opt.amg_full_levels, (int)amg->lv.size() - 1, 8}) : 0;
+    if (nratio > 0) TP_HIP(hipMemsetAsync(amg->ratio_dev.p, 0, sizeof(double) * 64 * nratio, c->stream));
     for (size_t l = 0; l < amg->lv.size(); ++l) {
         AmgLevel *L = amg->lv[l];
         const StencilT<R> op{(R *)L->op.base, L->op.slot_stride};
         hipLaunchKernelGGL(k_amg_weights<R>, grid_for(L->g.nown), dim3(256), 0, c->stream, L->g, op, L->axis,
-                           c->opt.amg_omega, (R *)L->wm.p, (R *)L->wp.p, (R *)L->invd.p);
+                           c->opt.amg_omega, (R *)L->wm.p, (R *)L->wp.p, (R *)L->invd.p,
+                           (int)l < nratio ? (unsigned long long *)amg->ratio_dev.p + 64 * l : (unsigned long long *)nullptr);
         if ((int)l < lg) {
             // distributed level: the cycle reads inverse diagonals and weights of the neighbours' boundary planes,
             // coarsening along the slab axis also their operator rows
@@ -845,7 +873,34 @@ static void setup_impl(tp_ctx *c, Amg *amg, const Stencil &A0) {
     for (size_t l = 0; l < amg->lv.size(); ++l) h.push_back(dev_of<R>(amg->lv[l], (int)l, c->opt));
     amg->lvhost.assign((const char *)h.data(), (const char *)h.data() + h.size() * sizeof(LevelDevT<R>));
     TP_HIP(hipMemcpyAsync(amg->lvdev.p, amg->lvhost.data(), amg->lvhost.size(), hipMemcpyHostToDevice, c->stream));
+    if (nratio > 0) {
+        TP_HIP(hipMemcpyAsync(amg->ratio_host, amg->ratio_dev.p, sizeof(double) * 64 * nratio, hipMemcpyDeviceToHost, c->stream));
+        TP_HIP(hipEventRecord(amg->ev_ratio, c->stream));
+        amg->ratio_pending = true;
+    } else if (amg->trunc != -1) {
+        amg->trunc = -1;
+        c->graph_epoch++;
+    }
     TP_HIP(hipGetLastError());
+}
+
+// Called before the first cycle after a set-up (never inside a stream capture): waits for the ratios and fixes the
+// truncation level.  Returns true when the cycle shape changed (captured pc_apply graphs are then stale).
+bool amg_resolve_trunc(tp_ctx *c, Amg *amg) {
+    if (!amg || !amg->ratio_pending) return false;
+    TP_HIP(hipEventSynchronize(amg->ev_ratio));
+    amg->ratio_pending = false;
+    const int nratio = std::min({c->opt.amg_full_levels, (int)amg->lv.size() - 1, 8});
+    int t = -1;
+    for (int l = 0; l < nratio; ++l) {
+        double r = 0.0;
+        for (int q = 0; q < 64; ++q) r = std::max(r, amg->ratio_host[64 * l + q]);
+        if (l == 0) amg->ratio0 = r;
+        if (r <= c->opt.amg_dom_tau) { t = l; break; }
+    }
+    const bool changed = t != amg->trunc;
+    amg->trunc = t;
+    return changed;
 }
 
 void amg_setup(tp_ctx *c, Amg *amg, const Stencil &A0) {
@@ -860,12 +915,15 @@ void amg_setup(tp_ctx *c, Amg *amg, const Stencil &A0) {
 template <class R>
 static void vcycle_impl(tp_ctx *c, Amg *amg, const double *b, double *x) {
     const int nlev = (int)amg->lv.size(), lt = amg->tail_level, lg = amg->dist_levels;
+    const int trunc = amg->trunc;               // >= 0: that level ends the cycle with two Jacobi sweeps (amg_dom_tau)
+    const int ltop = (trunc >= 0 && trunc < lt) ? trunc : lt;      // big levels [0, ltop) run their normal down/up sweeps
     const dim3 bl(256);
     std::vector<double *> xs(nlev, nullptr);       // pre-smoothed iterate of each big level (null: none)
     // level l (smoothed, no pre-sweeps) + level l+1 (pure transfer): both transfers in one launch each way
     static const bool pair_on = !(getenv("TP_AMG_PAIR") && atoi(getenv("TP_AMG_PAIR")) == 0);
     auto paired = [&](int l) {
         if (!pair_on || l < lg || l + 2 > lt || amg->lv[l]->g.nown >= amg->fuse_below) return false;
+        if (trunc >= 0 && l + 2 > trunc) return false;          // (the truncation level is among the V(nu,nu) levels: never paired)
         const LevelDevT<R> A = dev_of<R>(amg->lv[l], l, c->opt), B = dev_of<R>(amg->lv[l + 1], l + 1, c->opt);
         return A.pre == 0 && A.post >= 1 && B.pre == 0 && B.post == 0;
     };
@@ -873,7 +931,7 @@ static void vcycle_impl(tp_ctx *c, Amg *amg, const double *b, double *x) {
         if (l < lg) halo_exchange(c, amg->lv[l]->g, const_cast<double *>(v), 1, 0);
     };
     // down-sweep over the big levels
-    for (int l = 0; l < lt; ++l) {
+    for (int l = 0; l < ltop; ++l) {
         AmgLevel *L = amg->lv[l];
         AmgLevel *Lc = amg->lv[l + 1];
         const LevelDevT<R> Ld = dev_of<R>(L, l, c->opt);
@@ -915,18 +973,24 @@ static void vcycle_impl(tp_ctx *c, Amg *amg, const double *b, double *x) {
         if (l + 1 == lg)        // restricted residual of every slab -> the replicated levels' right-hand side
             gather_ranges(c, Lc->b.p, Lc->g.np, amg->ranges[lg], 1, 0, sizeof(double));
     }
-    // the tail: every level from lt down to the coarsest and back, one launch
-    {
+    if (trunc >= 0 && trunc < lt) {
+        // relaxation-only big level: x = x1 + invd (b - A x1), x1 = invd b (the fused double sweep), nothing below it
+        AmgLevel *L = amg->lv[trunc];
+        const double *bt = (trunc == 0) ? b : L->b.p;
+        double *et = (trunc == 0) ? x : L->e.p;
+        hipLaunchKernelGGL(k_amg_pre<R>, xcd_grid(L->g.nown), bl, 0, c->stream, dev_of<R>(L, trunc, c->opt), bt, 1, et);
+    } else {
+        // the tail: every level from lt down to the coarsest (or the truncation level) and back, one launch
         AmgLevel *Lt = amg->lv[lt];
         const double *bt = (lt == 0) ? b : Lt->b.p;
         double *et = (lt == 0) ? x : Lt->e.p;
         const int n = amg->ncoarse;
         hipLaunchKernelGGL(k_amg_tail<R>, dim3(1), dim3(1024), (size_t)4 * amg->tail_lds * sizeof(double), c->stream,
-                           (const LevelDevT<R> *)amg->lvdev.p, lt, nlev, c->opt.amg_nu, n,
+                           (const LevelDevT<R> *)amg->lvdev.p, lt, nlev, trunc, n,
                            (const double *)(amg->coarse_inv.p + (size_t)n * n), bt, et, amg->tail_lds);
     }
     // up-sweep over the big levels
-    for (int l = lt - 1; l >= 0; --l) {
+    for (int l = ltop - 1; l >= 0; --l) {
         AmgLevel *L = amg->lv[l];
         AmgLevel *Lc = amg->lv[l + 1];
         const LevelDevT<R> Ld = dev_of<R>(L, l, c->opt);
@@ -973,6 +1037,7 @@ static void vcycle_impl(tp_ctx *c, Amg *amg, const double *b, double *x) {
 
 void amg_vcycle(tp_ctx *c, Amg *amg, const double *b, double *x) {
     TP_REQUIRE(amg && !amg->lv.empty(), "AMG not set up");
+    TP_REQUIRE(!amg->ratio_pending, "amg_resolve_trunc must run after a set-up and before the first cycle");
     TP_REQUIRE(x != amg->lv[0]->x.p && x != amg->lv[0]->x2.p && b != x, "aliasing in amg_vcycle");
     if (amg->single) vcycle_impl<float>(c, amg, b, x);
     else vcycle_impl<double>(c, amg, b, x);

@@ -311,6 +311,7 @@ int tp_set_options(tp_ctx *c, const tp_options *opt) {
                              opt->amg_nu != c->opt.amg_nu || opt->amg_full_levels != c->opt.amg_full_levels ||
                              opt->amg_coarse_pre != c->opt.amg_coarse_pre || opt->amg_coarse_post != c->opt.amg_coarse_post ||
                              opt->amg_tail_post != c->opt.amg_tail_post || opt->amg_mid_skip != c->opt.amg_mid_skip ||
+                             opt->amg_dom_tau != c->opt.amg_dom_tau ||
                              opt->amg_single != c->opt.amg_single || opt->amg_gather_cells != c->opt.amg_gather_cells ||
                              opt->schur_a11 != c->opt.schur_a11;
     c->opt = *opt;
@@ -712,6 +713,7 @@ int tp_amg_vcycle(tp_ctx *c, int32_t which, int32_t field_b, int32_t b, int32_t 
     }
     Amg *amg = which == 0 ? c->amg_p : c->amg_T;
     TP_REQUIRE(amg, "this AMG hierarchy does not exist for the selected preconditioner");
+    resolve_cycle_shapes(c);
     TP_REQUIRE(!c->dist || amg->dist_levels > 0, "tp_amg_vcycle works on slab vectors: not available when the hierarchy is replicated on the gathered global grid");
     TP_REQUIRE(field_b >= 0 && field_b < c->b && field_x >= 0 && field_x < c->b, "bad field index");
     TP_REQUIRE(!(b == x && field_b == field_x), "b and x must differ");
@@ -722,6 +724,7 @@ int tp_amg_vcycle(tp_ctx *c, int32_t which, int32_t field_b, int32_t b, int32_t 
 int tp_schur_apply(tp_ctx *c, int32_t x, int32_t y) {
     TP_API_BEGIN
     TP_REQUIRE(c->pc_ready && c->amg_T, "S~ AMG not set up (pc_cptr only)");
+    resolve_cycle_shapes(c);
     TP_REQUIRE(!c->dist || c->amg_T->dist_levels > 0, "tp_schur_apply works on slab vectors: not available when the hierarchy is replicated on the gathered global grid");
     TP_REQUIRE(x != y, "x and y must differ");
     amg_vcycle(c, c->amg_T, vec_of(c, x).p + c->g.ntot, vec_of(c, y).p + c->g.ntot);
@@ -760,6 +763,7 @@ int tp_time_kernel(tp_ctx *c, int32_t which, int32_t reps, double *ms_avg) {
             case 0: spmv_block(c, c->J.p, c->R.p, c->w2.p); break;
             case 1: ilu_solve(c, c->R.p, c->w2.p, nullptr); break;
             case 2:
+                resolve_cycle_shapes(c);
                 if (sysamg_of(c->opt)) { TP_REQUIRE(!c->dist, "single slab only"); bamg_vcycle(c, c->bamg, c->R.p, c->w2.p); break; }
                 if (c->dist && c->amg_p->dist_levels == 0) amg_vcycle(c, c->amg_p, c->gvec.p, c->gvec.p + 2 * c->gfull.ntot);   // global-grid buffers
                 else amg_vcycle(c, c->amg_p, c->R.p, c->w2.p);
@@ -807,6 +811,16 @@ int tp_amg_info(tp_ctx *c, int32_t which, int32_t *nlevels, double *op_complexit
         if (l == 0) s0 = cells;
     }
     if (op_complexity) *op_complexity = s / s0;
+    TP_API_END
+}
+
+int tp_amg_trunc(tp_ctx *c, int32_t which, int32_t *level, double *ratio0) {
+    TP_API_BEGIN
+    Amg *amg = which == 0 ? c->amg_p : c->amg_T;
+    TP_REQUIRE(amg, "AMG hierarchy not built");
+    resolve_cycle_shapes(c);
+    if (level) *level = amg->trunc;
+    if (ratio0) *ratio0 = amg->ratio0;
     TP_API_END
 }
 

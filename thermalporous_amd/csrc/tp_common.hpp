@@ -153,10 +153,22 @@ struct Amg {
     // below on the gathered global grid, replicated on every rank.  0 = the whole hierarchy is replicated.
     int dist_levels = 0;
     std::vector<std::vector<std::pair<int, int>>> ranges;   // [level][rank] -> owned global planes along axis 2
+    // relaxation-only truncation (tp_options.amg_dom_tau): dominance ratios of the V(nu,nu) levels, measured by the set-up
+    // kernels into 64 slots per level (spread atomics), copied to pinned host memory behind `ev_ratio`
+    DBuf<double> ratio_dev;
+    double *ratio_host = nullptr;
+    hipEvent_t ev_ratio = nullptr;
+    bool ratio_pending = false;
+    int trunc = -1;            // level that ends the cycle with two Jacobi sweeps (-1: none)
+    double ratio0 = 0.0;
     DBuf<char> lvdev;          // device array of level descriptors (LevelDev) for the tail kernel
     std::vector<char> lvhost;
     std::vector<int> sched;
-    ~Amg() { for (auto *l : lv) delete l; }
+    ~Amg() {
+        for (auto *l : lv) delete l;
+        if (ratio_host) (void)hipHostFree(ratio_host);
+        if (ev_ratio) (void)hipEventDestroy(ev_ratio);
+    }
 };
 
 struct IluData {
@@ -264,6 +276,7 @@ void ilu_solve(tp_ctx *c, const double *r, double *x, const double *addto, int n
 void amg_build(tp_ctx *c, Amg *&amg, const GridDev &g0, const double strength[3]);
 void amg_setup(tp_ctx *c, Amg *amg, const Stencil &A0);
 void amg_vcycle(tp_ctx *c, Amg *amg, const double *b, double *x);
+bool amg_resolve_trunc(tp_ctx *c, Amg *amg);      // waits for the set-up's dominance ratios; true if the cycle shape changed
 // system AMG (2x2 blocks on (p,T))
 void bamg_build(tp_ctx *c, BAmg *&amg, const GridDev &g0, const double strength[3]);
 void bamg_setup(tp_ctx *c, BAmg *amg, const BStencil &A0);
@@ -280,6 +293,7 @@ void slab_of(const tp_ctx *c, int rank, int &lo, int &hi);
 // gather `nplanes` slab-distributed cell planes into arrays on the global grid (every rank gets all slabs)
 void gather_slabs(tp_ctx *c, const double *local, long lstride, double *global, long gstride, int nplanes);
 // solver
+void resolve_cycle_shapes(tp_ctx *c);     // fix the AMG truncation levels after a set-up (host wait; never in a capture)
 void ensure_work(tp_ctx *c);          // scratch vectors w1..w4, dx of the preconditioner / Krylov loops
 void pc_setup(tp_ctx *c);
 void stage1_apply(tp_ctx *c, const double *x, double *y, bool zero_secondary = true);

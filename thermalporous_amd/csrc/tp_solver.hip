@@ -196,11 +196,19 @@ void pc_setup(tp_ctx *c) {
     refresh_pc_signature(c);
 }
 
+// the relaxation-only truncation level of each hierarchy is known once its set-up kernels have run
+void resolve_cycle_shapes(tp_ctx *c) {
+    bool changed = amg_resolve_trunc(c, c->amg_p);
+    changed = amg_resolve_trunc(c, c->amg_T) || changed;
+    if (changed) c->graph_epoch++;
+}
+
 // y = B1 x :  CPRStage1PC.apply (preconditioners.py:881-903) / CPTRStage1PC.apply (:1550-1567)
 void stage1_apply(tp_ctx *c, const double *x, double *y, bool zero_secondary) {
     const GridDev &g = c->g;
     const long nt = g.ntot;
     ensure_work(c);
+    resolve_cycle_shapes(c);
     double *r0 = c->w3.p, *r1 = c->w3.p + nt, *t = c->w3.p + 2 * nt;   // w3 has >= 3 planes
     // y_s = 0 for the non-primary fields (:902-903, :1566-1567)
     const int npri = npri_of(c->opt);
@@ -290,6 +298,7 @@ void pc_apply(tp_ctx *c, const double *x, double *y) {
     static const bool use_graph = !(getenv("TP_GRAPH") && atoi(getenv("TP_GRAPH")) == 0);
     c->vcycles += schur_of(c->opt) ? 3 : 1;
     ensure_work(c);                      // never allocate inside a stream capture
+    resolve_cycle_shapes(c);             // (waits for the last set-up's dominance ratios: not inside a capture either)
     if (!use_graph || c->dist) {
         pc_apply_body(c, x, y);
         return;

@@ -45,7 +45,7 @@ class tp_options(C.Structure):
                 ("amg_omega", C.c_double), ("amg_nu", C.c_int32), ("amg_min_cells", C.c_int32),
                 ("ilu_t1", C.c_int32), ("ilu_t2", C.c_int32), ("ilu_t0", C.c_int32),
                 ("amg_full_levels", C.c_int32), ("amg_coarse_pre", C.c_int32), ("amg_coarse_post", C.c_int32),
-                ("amg_mid_skip", C.c_int32), ("amg_tail_post", C.c_int32), ("amg_single", C.c_int32), ("schur_a11", C.c_int32), ("amg_gather_cells", C.c_int32)]
+                ("amg_mid_skip", C.c_int32), ("amg_tail_post", C.c_int32), ("amg_single", C.c_int32), ("schur_a11", C.c_int32), ("amg_gather_cells", C.c_int32), ("amg_dom_tau", C.c_double)]
 
 
 class tp_solve_info(C.Structure):
@@ -62,7 +62,7 @@ API_SYMBOLS = (
     "tp_residual", "tp_jacobian", "tp_get_residual", "tp_export_jacobian", "tp_export_schur",
     "tp_well_rates", "tp_vec_create", "tp_vec_create_batch", "tp_vec_dot_batch", "tp_vec_axpy_batch", "tp_vec_norm2", "tp_set_ksp_monitor", "tp_vec_set", "tp_vec_get", "tp_vec_copy_residual", "tp_spmv", "tp_pc_setup",
     "tp_pc_apply", "tp_stage1_update", "tp_stage1_apply", "tp_ilu0_factor", "tp_ilu0_solve", "tp_amg_setup",
-    "tp_amg_vcycle", "tp_schur_apply", "tp_fgmres", "tp_newton_solve", "tp_time_kernel", "tp_amg_info", "tp_amg_layout",
+    "tp_amg_vcycle", "tp_schur_apply", "tp_fgmres", "tp_newton_solve", "tp_time_kernel", "tp_amg_info", "tp_amg_layout", "tp_amg_trunc",
 )
 
 DEFAULT_OPTS = dict(
@@ -70,6 +70,7 @@ DEFAULT_OPTS = dict(
     ksp_rtol=1e-7, ksp_atol=1e-50, ksp_max_it=200, ksp_restart=200,
     snes_rtol=1e-8, snes_atol=1e-50, snes_stol=1e-8, snes_max_it=15,
     amg_omega=0.8, amg_min_cells=64, amg_nu=2, amg_full_levels=3, amg_coarse_pre=0, amg_coarse_post=1, amg_mid_skip=True, amg_tail_post=2, amg_single=False,
+    amg_dom_tau=0.25,       # relaxation-only truncation of diagonally dominant AMG hierarchies (oracle/linalg.py:SemiAMG)
     amg_gather_cells=2000000,
     schur_a11=False,
     ilu_tile=None,          # None: whole axis-0 lines x 8 x 8 columns (3-D), x 32 columns (2-D); see default_ilu_tile
@@ -248,7 +249,7 @@ class HipEngine:
                           o["amg_omega"], o["amg_nu"], o["amg_min_cells"], int(min(t[1], 64)), int(min(t[2], 64)),
                           0 if t[0] >= (1 << 30) else int(t[0]), int(o["amg_full_levels"]), int(o["amg_coarse_pre"]),
                           int(o["amg_coarse_post"]), int(bool(o["amg_mid_skip"])), int(o["amg_tail_post"]), int(bool(o["amg_single"])), int(bool(o["schur_a11"])),
-                          int(o["amg_gather_cells"]))
+                          int(o["amg_gather_cells"]), float(o.get("amg_dom_tau", 0.0)))
 
     def set_options(self, **kw):
         self.opts.update(kw)
@@ -460,6 +461,12 @@ class HipEngine:
         nl, oc = C.c_int32(), C.c_double()
         self._ck(self.lib.tp_amg_info(self.ctx, which, C.byref(nl), C.byref(oc)))
         return nl.value, oc.value
+
+    def amg_trunc(self, which=0):
+        """(level at which hierarchy `which` ends with relaxation only, -1 = full V-cycle; level-0 dominance ratio)."""
+        lv, r0 = C.c_int32(), C.c_double()
+        self._ck(self.lib.tp_amg_trunc(self.ctx, which, C.byref(lv), C.byref(r0)))
+        return lv.value, r0.value
 
     def amg_layout(self, which=0):
         """(number of slab-distributed top levels, coarsening axis of every level)."""
