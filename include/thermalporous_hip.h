@@ -98,6 +98,9 @@ typedef struct tp_options {
                                 sweeps (no coarse-grid correction: damped Jacobi already contracts by
                                 1 - omega (1 - tau) per sweep there; BoomerAMG's max_row_sum rule for diagonally dominant
                                 rows).  Hits the temperature operator S~ of pc_cptr, never the pressure.  0: off. */
+    int32_t ilu_levels;      /* stage 2 fill level: 0 = block-ILU(0) (sub_1_sub_pc_factor_levels 0, the presets' default),
+                                1 = block-ILU(1) (pc_cprilu1_gmres, twophase.py:653-668): 13-block rows, the sweeps
+                                take 4 steps of skew per axis-2 plane and 2 per axis-1 line instead of 1 and 1 */
 } tp_options;
 
 /* Result of one nonlinear solve (SNES iteration number / linear iterations / reason:

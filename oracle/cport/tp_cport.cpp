@@ -98,6 +98,7 @@ struct Opts {
     int32_t tile[3];
     int32_t nslabs;
     double amg_dom_tau;
+    int32_t ilu_levels;   // 0 or 1 (sub_1_sub_pc_factor_levels)
 };
 
 struct Info {
@@ -508,6 +509,7 @@ struct Ctx {
     int tile[3];
     std::vector<int> l0, l1, l2, td0, td1, td2;       // in-tile coordinates and tile extents per cell
     std::vector<std::vector<long>> tiles;             // cells of each tile in natural order
+    vec F1;                                           // ILU(1): 13 blocks per cell (6 lower, D~^-1, 6 upper)
     vec Dinv, Bf, Cb;                                 // D~^-1 ; B_cm = A_cm D~_m^-1 (3/cell) ; C_cm = D~_c^-1 A_up (3/cell)
     // AMG
     SemiAMG amg_p, amg_T;
@@ -1013,6 +1015,135 @@ static void ilu_solve_t(const Ctx &C, const double *r, double *x, double *y) {
     }
 }
 
+// ---------------------------------------------------------------- tiled block ILU(1)  (oracle.linalg.TiledILU1)
+// factor pattern of a row: 6 lower offsets (increasing global index), the diagonal, 6 upper offsets; (d0, d1, d2)
+static const int ILU1_OFF[13][3] = {{0, 0, -1}, {1, 0, -1}, {0, 1, -1}, {0, -1, 0}, {1, -1, 0}, {-1, 0, 0}, {0, 0, 0},
+                                    {1, 0, 0},  {-1, 1, 0}, {0, 1, 0},  {0, -1, 1}, {-1, 0, 1}, {0, 0, 1}};
+static int ilu1_find(int d0, int d1, int d2) {
+    for (int i = 0; i < 13; ++i)
+        if (ILU1_OFF[i][0] == d0 && ILU1_OFF[i][1] == d1 && ILU1_OFF[i][2] == d2) return i;
+    return -1;
+}
+static int ilu1_slot(int i) {          // stencil slot of a pattern entry, -1 for the level-1 fill entries
+    const int *o = ILU1_OFF[i];
+    if (std::abs(o[0]) + std::abs(o[1]) + std::abs(o[2]) > 1) return -1;
+    if (o[0]) return o[0] < 0 ? 1 : 2;
+    if (o[1]) return o[1] < 0 ? 3 : 4;
+    if (o[2]) return o[2] < 0 ? 5 : 6;
+    return 0;
+}
+static bool ilu1_inside(const Ctx &C, long c, int i) {
+    const int a0 = C.l0[c] + ILU1_OFF[i][0], a1 = C.l1[c] + ILU1_OFF[i][1], a2 = C.l2[c] + ILU1_OFF[i][2];
+    return a0 >= 0 && a0 < C.td0[c] && a1 >= 0 && a1 < C.td1[c] && a2 >= 0 && a2 < C.td2[c];
+}
+static long ilu1_off(const Ctx &C, int i) {
+    return ILU1_OFF[i][0] * C.g.st[0] + ILU1_OFF[i][1] * C.g.st[1] + ILU1_OFF[i][2] * C.g.st[2];
+}
+
+template <int B>
+static void ilu1_factor_t(Ctx &C) {
+    const int BB = B * B;
+    const long nt = (long)C.tiles.size();
+    C.F1.resize((size_t)13 * BB * C.g.N);
+    int target[6][6];
+    for (int ik = 0; ik < 6; ++ik)
+        for (int iu = 0; iu < 6; ++iu)
+            target[ik][iu] = ilu1_find(ILU1_OFF[ik][0] + ILU1_OFF[7 + iu][0], ILU1_OFF[ik][1] + ILU1_OFF[7 + iu][1],
+                                       ILU1_OFF[ik][2] + ILU1_OFF[7 + iu][2]);
+#pragma omp parallel for schedule(dynamic, 1)
+    for (long t = 0; t < nt; ++t) {
+        for (long c : C.tiles[t]) {
+            double F[13][BB];
+            bool in[13];
+            for (int i = 0; i < 13; ++i) {
+                in[i] = ilu1_inside(C, c, i);
+                const int sl = ilu1_slot(i);
+                for (int r = 0; r < B; ++r)
+                    for (int q = 0; q < B; ++q) F[i][r * B + q] = (in[i] && sl >= 0) ? C.Jat(sl, r, q, c) : 0.0;
+            }
+            for (int ik = 0; ik < 6; ++ik) {
+                if (!in[ik]) continue;
+                const long k = c + ilu1_off(C, ik);
+                const double *Fk = &C.F1[(size_t)k * 13 * BB];
+                double Lck[BB];
+                for (int r = 0; r < B; ++r)
+                    for (int q = 0; q < B; ++q) {
+                        double v = 0.0;
+                        for (int m = 0; m < B; ++m) v += F[ik][r * B + m] * Fk[6 * BB + m * B + q];
+                        Lck[r * B + q] = v;
+                    }
+                for (int e = 0; e < BB; ++e) F[ik][e] = Lck[e];
+                for (int iu = 0; iu < 6; ++iu) {
+                    const int tg = target[ik][iu];
+                    if (tg < 0) continue;
+                    const double *U = Fk + (size_t)(7 + iu) * BB;       // zero where (k, j) leaves the tile
+                    for (int r = 0; r < B; ++r)
+                        for (int q = 0; q < B; ++q) {
+                            double v = 0.0;
+                            for (int m = 0; m < B; ++m) v += Lck[r * B + m] * U[m * B + q];
+                            F[tg][r * B + q] -= v;
+                        }
+                }
+            }
+            double *out = &C.F1[(size_t)c * 13 * BB];
+            for (int i = 0; i < 13; ++i)
+                if (i != 6) for (int e = 0; e < BB; ++e) out[i * BB + e] = F[i][e];
+            inv_block<B>(F[6], out + 6 * BB);
+        }
+    }
+}
+
+template <int B>
+static void ilu1_solve_t(const Ctx &C, const double *r, double *x, double *y) {
+    const long N = C.g.N;
+    const int BB = B * B;
+    const long nt = (long)C.tiles.size();
+    long off[13];
+    for (int i = 0; i < 13; ++i) off[i] = ilu1_off(C, i);
+#pragma omp parallel for schedule(dynamic, 1)
+    for (long t = 0; t < nt; ++t) {
+        const std::vector<long> &cells = C.tiles[t];
+        for (long c : cells) {                               // L y = r
+            const double *Fc = &C.F1[(size_t)c * 13 * BB];
+            double v[B];
+            for (int q = 0; q < B; ++q) v[q] = r[q * N + c];
+            for (int i = 0; i < 6; ++i) {
+                if (!ilu1_inside(C, c, i)) continue;
+                const long m = c + off[i];
+                for (int q = 0; q < B; ++q)
+                    for (int k = 0; k < B; ++k) v[q] -= Fc[i * BB + q * B + k] * y[k * N + m];
+            }
+            for (int q = 0; q < B; ++q) y[q * N + c] = v[q];
+        }
+        for (long ii = (long)cells.size() - 1; ii >= 0; --ii) {  // U x = y
+            const long c = cells[ii];
+            const double *Fc = &C.F1[(size_t)c * 13 * BB];
+            double v[B];
+            for (int q = 0; q < B; ++q) v[q] = y[q * N + c];
+            for (int i = 7; i < 13; ++i) {
+                if (!ilu1_inside(C, c, i)) continue;
+                const long m = c + off[i];
+                for (int q = 0; q < B; ++q)
+                    for (int k = 0; k < B; ++k) v[q] -= Fc[i * BB + q * B + k] * x[k * N + m];
+            }
+            for (int q = 0; q < B; ++q) {
+                double sacc = 0.0;
+                for (int k = 0; k < B; ++k) sacc += Fc[6 * BB + q * B + k] * v[k];
+                x[q * N + c] = sacc;
+            }
+        }
+    }
+}
+
+static void ilu_factor_any(Ctx &C) {
+    if (C.o.ilu_levels == 1) { if (C.b == 3) ilu1_factor_t<3>(C); else ilu1_factor_t<2>(C); }
+    else                     { if (C.b == 3) ilu_factor_t<3>(C); else ilu_factor_t<2>(C); }
+}
+static void ilu_solve_any(const Ctx &C, const double *r, double *x, double *y) {
+    if (C.o.ilu_levels == 1) { if (C.b == 3) ilu1_solve_t<3>(C, r, x, y); else ilu1_solve_t<2>(C, r, x, y); }
+    else                     { if (C.b == 3) ilu_solve_t<3>(C, r, x, y); else ilu_solve_t<2>(C, r, x, y); }
+}
+
 // ---------------------------------------------------------------- stage 1 (oracle.linalg.decouple / TwoStagePC)
 static void colsum(const Ctx &C, int q, int s, double *out) {      // column sums of block (q, s) == (A^T 1)
     const long N = C.g.N;
@@ -1047,7 +1178,7 @@ static void pc_setup(Ctx &C) {
     const long N = C.g.N;
     const int b = C.b;
     if (C.tiles.empty()) ilu_layout(C);
-    if (b == 3) ilu_factor_t<3>(C); else ilu_factor_t<2>(C);
+    ilu_factor_any(C);
     const int npri = C.o.pc == 0 ? 1 : 2;
     C.have_d = C.o.decoup != 0;
     if (C.have_d) {
@@ -1158,7 +1289,7 @@ static void pc_apply(Ctx &C, const double *x, double *y) {      // TwoStagePC.ap
 #pragma omp parallel for schedule(static)
     for (long i = 0; i < (long)b * N; ++i) r[i] = x[i] - r[i];
     if (C.w_yt.size() != (size_t)b * N) C.w_yt.assign((size_t)b * N, 0.0);
-    if (b == 3) ilu_solve_t<3>(C, r, z, C.w_yt.data()); else ilu_solve_t<2>(C, r, z, C.w_yt.data());
+    ilu_solve_any(C, r, z, C.w_yt.data());
 #pragma omp parallel for schedule(static)
     for (long i = 0; i < (long)b * N; ++i) y[i] = y[i] + z[i];
 }
@@ -1432,7 +1563,7 @@ void cp_spmv(void *c, const double *x, double *y) { spmv_block(*(Ctx *)c, x, y);
 void cp_ilu_solve(void *c, const double *r, double *x) {
     Ctx *C = (Ctx *)c;
     vec y((size_t)C->b * C->g.N);
-    if (C->b == 3) ilu_solve_t<3>(*C, r, x, y.data()); else ilu_solve_t<2>(*C, r, x, y.data());
+    ilu_solve_any(*C, r, x, y.data());
 }
 void cp_vcycle(void *c, int which, const double *b, double *x) {
     Ctx *C = (Ctx *)c;

@@ -4,7 +4,7 @@ What the reference delegates to PETSc/hypre, restated so 
 kernels have a CPU checker computing the SAME algorithm:
   * MatMult on the 7-point block stencil                      (PETSc MatMult AIJ)
   * stage 2: block-Jacobi over tiles + block-ILU(0) per tile   (sub_1_* bjacobi/ilu levels 0,
-    singlephase.py:348-349, twophase.py:547-548; ``-sub_1_pc_bjacobi_blocks`` tests/test_homo_wells.py:112,125)
+    singlephase.py:348-349, twophase.py:547-548; levels 1: twophase.py:653-668; ``-sub_1_pc_bjacobi_blocks`` tests/test_homo_wells.py:112,125)
   * stage 1 operators: Quasi-/True-IMPES decoupling            (preconditioners.py:684-711,785-808,1445-1543)
   * pressure / temperature AMG V-cycle                         (v_cycle dicts singlephase.py:303-307)
   * fieldsplit Schur FULL apply for pc_cptr                    (twophase.py:536-545)
@@ -157,6 +157,93 @@ class TiledILU0:
                     continue
                 nb = cc + self.strides[a]
                 t[:, m] -= np.einsum("ijn,jn->in", Jf[2 + 2 * a][:, :, cc], x[:, nb])
+            x[:, c] = np.einsum("ijn,jn->in", Dinv[:, :, c], t)
+        return x.reshape(r.shape)
+
+
+class TiledILU1(TiledILU0):
+    """Block-Jacobi over box tiles, block-ILU(1) in natural order inside each tile
+    (sub_1_sub_pc_factor_levels 1: twophase.py:665-666 pc_cprilu1_gmres).
+
+    Level-1 fill on the 7-point cell graph in natural order: a lower neighbour k of cell c and an upper neighbour
+    j of k give a new entry (c, j) when j is not already coupled to c.  The factor pattern of a row is therefore
+    the 13 offsets below (6 lower, diagonal, 6 upper; (d0, d1, d2) along axes 0, 1, 2), the numeric phase is the
+    IKJ elimination restricted to that pattern (what PETSc's MatLUFactorNumeric does on the symbolic ILU(k)
+    pattern), blocks are dense b x b, and entries that leave the tile do not exist.  M = L U with L unit lower.
+    Cells with equal l0 + 2*l1 + 4*l2 (tile-local coordinates) are mutually independent, all rows a row
+    depends on have a smaller value: that is the sweep order here and on the GPU."""
+    LOWER = [(0, 0, -1), (1, 0, -1), (0, 1, -1), (0, -1, 0), (1, -1, 0), (-1, 0, 0)]     # increasing global index
+    UPPER = [(1, 0, 0), (-1, 1, 0), (0, 1, 0), (0, -1, 1), (-1, 0, 1), (0, 0, 1)]
+    SLOT = {(-1, 0, 0): 1, (1, 0, 0): 2, (0, -1, 0): 3, (0, 1, 0): 4, (0, 0, -1): 5, (0, 0, 1): 6, (0, 0, 0): 0}
+
+    def __init__(self, shape, tile, slabs=None):
+        super().__init__(shape, tile, slabs)
+        self.level = (self.l[0] + 2 * self.l[1] + 4 * self.l[2]).reshape(-1)
+        self.nlev = int(self.level.max()) + 1
+        order = np.argsort(self.level, kind="stable")
+        bounds = np.searchsorted(self.level[order], np.arange(self.nlev + 1))
+        self.cells_at = [order[bounds[s]:bounds[s + 1]] for s in range(self.nlev)]
+        lf = [x.reshape(-1) for x in self.l]
+        td = [x.reshape(-1) for x in self.tdim]
+        self.inside = {}
+        for o in self.LOWER + self.UPPER + [(0, 0, 0)]:
+            m = np.ones(lf[0].shape, dtype=bool)
+            for a in range(3):
+                m &= (lf[a] + o[a] >= 0) & (lf[a] + o[a] < td[a])
+            self.inside[o] = m
+        self.off = {o: o[0] * self.strides[0] + o[1] * self.strides[1] + o[2] * self.strides[2] for o in self.inside}
+
+    def factor(self, J):
+        b = J.shape[1]
+        n = int(np.prod(self.shape))
+        Jf = J.reshape(7, b, b, n)
+        F = {}
+        for o in self.inside:
+            F[o] = np.zeros((b, b, n))
+            if o in self.SLOT:
+                F[o][:, :, self.inside[o]] = Jf[self.SLOT[o]][:, :, self.inside[o]]
+        Dinv = np.zeros((b, b, n))
+        for s in range(self.nlev):
+            c = self.cells_at[s]
+            for ok in self.LOWER:
+                cc = c[self.inside[ok][c]]
+                if len(cc) == 0:
+                    continue
+                k = cc + self.off[ok]
+                Lck = np.einsum("ijn,jkn->ikn", F[ok][:, :, cc], Dinv[:, :, k])
+                F[ok][:, :, cc] = Lck
+                for oj in self.UPPER:
+                    o = (ok[0] + oj[0], ok[1] + oj[1], ok[2] + oj[2])
+                    if o in F:            # (k, j) entries that leave the tile are stored as zeros
+                        F[o][:, :, cc] -= np.einsum("ijn,jkn->ikn", Lck, F[oj][:, :, k])
+            Dinv[:, :, c] = np.linalg.inv(F[(0, 0, 0)][:, :, c].transpose(2, 0, 1)).transpose(1, 2, 0)
+        self.F, self.Dinv = F, Dinv
+        return self
+
+    def solve(self, r):
+        b = self.Dinv.shape[0]
+        n = int(np.prod(self.shape))
+        F, Dinv = self.F, self.Dinv
+        rf = r.reshape(b, n)
+        y = np.zeros((b, n))
+        for s in range(self.nlev):                     # L y = r
+            c = self.cells_at[s]
+            t = rf[:, c].copy()
+            for o in self.LOWER:
+                m = self.inside[o][c]
+                cc = c[m]
+                if len(cc):
+                    t[:, m] -= np.einsum("ijn,jn->in", F[o][:, :, cc], y[:, cc + self.off[o]])
+            y[:, c] = t
+        x = np.zeros((b, n))
+        for s in range(self.nlev - 1, -1, -1):         # U x = y
+            c = self.cells_at[s]
+            t = y[:, c].copy()
+            for o in self.UPPER:
+                m = self.inside[o][c]
+                cc = c[m]
+                if len(cc):
+                    t[:, m] -= np.einsum("ijn,jn->in", F[o][:, :, cc], x[:, cc + self.off[o]])
             x[:, c] = np.einsum("ijn,jn->in", Dinv[:, :, c], t)
         return x.reshape(r.shape)
 
@@ -571,7 +658,10 @@ class TwoStagePC:
             if opts["pc"] in ("cptr", "fieldsplit_cd") else None
         # pc_cptramg: ONE system V-cycle on the (p,T) 2x2-block operator (coarsening schedule of the pressure)
         self.amg_pT = BlockSemiAMG(n, st, nb=2, **kw) if opts["pc"] == "cptramg" else None
-        self.ilu = TiledILU0(shape, opts["ilu_tile"], self.slabs)
+        levels = int(opts.get("ilu_levels", 0))
+        if levels not in (0, 1):
+            raise ValueError("ilu_levels must be 0 or 1")
+        self.ilu = (TiledILU1 if levels else TiledILU0)(shape, opts["ilu_tile"], self.slabs)
         self.vcycles = 0
 
     def setup(self, J, Sm=None):

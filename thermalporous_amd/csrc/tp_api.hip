@@ -306,7 +306,9 @@ int tp_destroy(tp_ctx *ctx) {
 int tp_set_options(tp_ctx *c, const tp_options *opt) {
     TP_API_BEGIN
     TP_REQUIRE(c && opt, "null argument");
-    const bool tile_changed = opt->ilu_t1 != c->opt.ilu_t1 || opt->ilu_t2 != c->opt.ilu_t2 || opt->ilu_t0 != c->opt.ilu_t0;
+    TP_REQUIRE(opt->ilu_levels == 0 || opt->ilu_levels == 1, "ilu_levels must be 0 or 1");
+    const bool tile_changed = opt->ilu_t1 != c->opt.ilu_t1 || opt->ilu_t2 != c->opt.ilu_t2 || opt->ilu_t0 != c->opt.ilu_t0 ||
+                              opt->ilu_levels != c->opt.ilu_levels;
     const bool amg_changed = opt->amg_min_cells != c->opt.amg_min_cells || opt->pc_kind != c->opt.pc_kind ||
                              opt->amg_nu != c->opt.amg_nu || opt->amg_full_levels != c->opt.amg_full_levels ||
                              opt->amg_coarse_pre != c->opt.amg_coarse_pre || opt->amg_coarse_post != c->opt.amg_coarse_post ||

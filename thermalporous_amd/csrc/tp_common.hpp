@@ -176,6 +176,7 @@ struct IluData {
     DBuf<double> fwd, bwd, ytmp;   // streaming factor data in consumption order
     DBuf<double> jt;               // the Jacobian blocks re-ordered the same way (input of the factorisation)
     long slots = 0;                // ntiles*nsteps*64
+    int levels = 0;                // 0: ILU(0), 1: ILU(1) (tp_options.ilu_levels; other chunk layout, see tp_ilu.hip)
 };
 
 }  // namespace tp

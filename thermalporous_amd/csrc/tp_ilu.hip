@@ -484,6 +484,293 @@ __global__ __launch_bounds__(64) void k_ilu_solve(IluGeom G, const double *__res
     }
 }
 
+// ---------------------------------------------------------------------------------------------------------------
+// Block-ILU(1) per tile (sub_1_sub_pc_factor_levels 1: pc_cprilu1_gmres, twophase.py:653-668).
+// Level-1 fill on the 7-point cell graph in natural order adds three lower and three upper couplings per row:
+// pattern = 6 lower offsets (in increasing global index), the diagonal, 6 upper offsets (oracle/linalg.py:TiledILU1).
+// One wavefront per tile as for ILU(0), lane <-> column (j,k), but the step of a cell is s = i0 + 2j + 4k: every row a
+// row depends on -- (i0-1,j,k), (i0,j-1,k), (i0+1,j-1,k), (i0,j,k-1), (i0+1,j,k-1), (i0,j+1,k-1) -- then has a smaller
+// step (s-1, s-2, s-1, s-4, s-3, s-2), so the sweeps keep the last FOUR results of every lane in registers and take the
+// neighbours' values by cross-lane shuffles.  Chunks are [tile][step][entry][64 lanes] doubles (512-byte rows).
+// The factorisation runs once per Newton step and is latency-, not bandwidth-bound: one launch per step value, each
+// thread eliminating one row against the rows of earlier launches (read back from the chunk arrays through L2).
+__host__ __device__ constexpr int ilu1_off(int i, int a) {
+    //            lower: -e2        -e2+e0       -e2+e1       -e1          -e1+e0       -e0        diag
+    constexpr int O[13][3] = {{0, 0, -1}, {1, 0, -1}, {0, 1, -1}, {0, -1, 0}, {1, -1, 0}, {-1, 0, 0}, {0, 0, 0},
+    //            upper: +e0        +e1-e0       +e1          +e2-e1       +e2-e0       +e2
+                              {1, 0, 0},  {-1, 1, 0}, {0, 1, 0},  {0, -1, 1}, {-1, 0, 1}, {0, 0, 1}};
+    return O[i][a];
+}
+__host__ __device__ constexpr int ilu1_find(int d0, int d1, int d2) {
+    for (int i = 0; i < 13; ++i)
+        if (ilu1_off(i, 0) == d0 && ilu1_off(i, 1) == d1 && ilu1_off(i, 2) == d2) return i;
+    return -1;
+}
+// pattern entry of (lower ik) + (upper iu), -1 when the product falls outside the pattern (level-2 fill: dropped)
+__host__ __device__ constexpr int ilu1_target(int ik, int iu) {
+    return ilu1_find(ilu1_off(ik, 0) + ilu1_off(7 + iu, 0), ilu1_off(ik, 1) + ilu1_off(7 + iu, 1),
+                     ilu1_off(ik, 2) + ilu1_off(7 + iu, 2));
+}
+// stencil slot of a pattern entry (-1: a fill entry, initially zero)
+__host__ __device__ constexpr int ilu1_slot(int i) {
+    const int d0 = ilu1_off(i, 0), d1 = ilu1_off(i, 1), d2 = ilu1_off(i, 2);
+    if ((d0 != 0) + (d1 != 0) + (d2 != 0) > 1) return -1;
+    return d0 ? (d0 < 0 ? 1 : 2) : d1 ? (d1 < 0 ? 3 : 4) : d2 ? (d2 < 0 ? 5 : 6) : 0;
+}
+
+__device__ __forceinline__ bool tile_cell1(const IluGeom &G, const TileInfo &t, int s, int &l0, long &c) {
+    l0 = s - 2 * t.j - 4 * t.k;
+    const bool ok = (t.k < G.t2) && (t.j < t.tj) && (t.k < t.tk) && (l0 >= 0) && (l0 < t.tt0);
+    c = G.g.np + (long)(t.base0 + l0) + (long)G.g.n0 * (t.base1 + t.j) + G.g.np * (t.base2 + t.k);
+    return ok;
+}
+
+template <int B, int I>
+struct Ilu1Init {          // row entries from the Jacobian (compile-time slot per pattern entry)
+    static __device__ __forceinline__ void run(double (&F)[13][B * B], const bool (&in)[13], const double *J, long nt, long c) {
+        constexpr int SL = ilu1_slot(I);
+#pragma unroll
+        for (int e = 0; e < B * B; ++e) F[I][e] = (SL >= 0 && in[I]) ? J[(long)((SL < 0 ? 0 : SL) * B * B + e) * nt + c] : 0.0;
+        if constexpr (I + 1 < 13) Ilu1Init<B, I + 1>::run(F, in, J, nt, c);
+    }
+};
+
+template <int B, int IK, int IU>
+struct Ilu1Upd {           // F[target(IK,IU)] -= L * U_k[IU]
+    static __device__ __forceinline__ void run(double (&F)[13][B * B], const double (&Lck)[B * B], const double *bk) {
+        constexpr int TG = ilu1_target(IK, IU);
+        if constexpr (TG >= 0) {
+            double U[B * B];
+#pragma unroll
+            for (int e = 0; e < B * B; ++e) U[e] = bk[(long)(IU * B * B + e) * 64];
+#pragma unroll
+            for (int r = 0; r < B; ++r)
+#pragma unroll
+                for (int q = 0; q < B; ++q) {
+                    double v = 0.0;
+#pragma unroll
+                    for (int m = 0; m < B; ++m) v += Lck[r * B + m] * U[m * B + q];
+                    F[TG][r * B + q] -= v;
+                }
+        }
+        if constexpr (IU + 1 < 6) Ilu1Upd<B, IK, IU + 1>::run(F, Lck, bk);
+    }
+};
+
+template <int B, int IK>
+struct Ilu1Elim {          // eliminate the lower entry IK of the row against row k = c + offset(IK)
+    static __device__ __forceinline__ void run(double (&F)[13][B * B], const bool (&in)[13], const IluGeom &G,
+                                               const double *bwd, long chunk0, int s, int lane) {
+        if (in[IK]) {
+            constexpr int d0 = ilu1_off(IK, 0), d1 = ilu1_off(IK, 1), d2 = ilu1_off(IK, 2);
+            const double *bk = bwd + (chunk0 + s + d0 + 2 * d1 + 4 * d2) * (long)(7 * B * B * 64) + (lane + d1 + G.t1 * d2);
+            double Dk[B * B], Lck[B * B];
+#pragma unroll
+            for (int e = 0; e < B * B; ++e) Dk[e] = bk[(long)(6 * B * B + e) * 64];
+#pragma unroll
+            for (int r = 0; r < B; ++r)
+#pragma unroll
+                for (int q = 0; q < B; ++q) {
+                    double v = 0.0;
+#pragma unroll
+                    for (int m = 0; m < B; ++m) v += F[IK][r * B + m] * Dk[m * B + q];
+                    Lck[r * B + q] = v;
+                }
+#pragma unroll
+            for (int e = 0; e < B * B; ++e) F[IK][e] = Lck[e];
+            Ilu1Upd<B, IK, 0>::run(F, Lck, bk);
+        }
+        if constexpr (IK + 1 < 6) Ilu1Elim<B, IK + 1>::run(F, in, G, bwd, chunk0, s, lane);
+    }
+};
+
+template <int B>
+__global__ __launch_bounds__(64) void k_ilu1_level(IluGeom G, const double *__restrict__ J, double *fwd, double *bwd, int s) {
+    constexpr int BB = B * B;
+    const int tile = blockIdx.x, lane = threadIdx.x;
+    const TileInfo ti = tile_info(G, tile, lane);
+    const long chunk0 = (long)tile * G.nsteps;
+    int l0;
+    long c;
+    const bool ok = tile_cell1(G, ti, s, l0, c);
+    double *fch = fwd + (chunk0 + s) * (long)(6 * BB * 64) + lane;
+    double *bch = bwd + (chunk0 + s) * (long)(7 * BB * 64) + lane;
+    if (!ok) {                       // no row here: zero blocks, so that the sweeps need no masks
+        for (int e = 0; e < 6 * BB; ++e) fch[(long)e * 64] = 0.0;
+        for (int e = 0; e < 7 * BB; ++e) bch[(long)e * 64] = 0.0;
+        return;
+    }
+    double F[13][BB];
+    bool in[13];
+#pragma unroll
+    for (int i = 0; i < 13; ++i) {
+        const int a0 = l0 + ilu1_off(i, 0), a1 = ti.j + ilu1_off(i, 1), a2 = ti.k + ilu1_off(i, 2);
+        in[i] = a0 >= 0 && a0 < ti.tt0 && a1 >= 0 && a1 < ti.tj && a2 >= 0 && a2 < ti.tk;
+    }
+    Ilu1Init<B, 0>::run(F, in, J, G.g.ntot, c);
+    Ilu1Elim<B, 0>::run(F, in, G, bwd, chunk0, s, lane);
+    double D[B][B], Di[B][B];
+#pragma unroll
+    for (int r = 0; r < B; ++r)
+#pragma unroll
+        for (int q = 0; q < B; ++q) D[r][q] = F[6][r * B + q];
+    inv_block<B>(D, Di);
+#pragma unroll
+    for (int i = 0; i < 6; ++i)
+#pragma unroll
+        for (int e = 0; e < BB; ++e) {
+            fch[(long)(i * BB + e) * 64] = F[i][e];
+            bch[(long)(i * BB + e) * 64] = F[7 + i][e];
+        }
+#pragma unroll
+    for (int r = 0; r < B; ++r)
+#pragma unroll
+        for (int q = 0; q < B; ++q) bch[(long)(6 * BB + r * B + q) * 64] = Di[r][q];
+}
+
+// x = addto + (L U)^-1 r for one tile per wavefront
+template <int B>
+__global__ __launch_bounds__(64) void k_ilu1_solve(IluGeom G, const double *__restrict__ fwd, const double *__restrict__ bwd,
+                                                   const double *__restrict__ rhs, double *__restrict__ ytmp, double *x,
+                                                   const double *addto, int nadd) {
+    constexpr int BB = B * B, NF = 6 * BB, NB = 7 * BB;
+    const int tile = blockIdx.x, lane = threadIdx.x;
+    const long nt = G.g.ntot;
+    const TileInfo ti = tile_info(G, tile, lane);
+    const long chunk0 = (long)tile * G.nsteps;
+    const int ns = G.nsteps;
+    const long park = min((long)lane, G.g.np - 1);     // an entry of the lower halo plane: what cell-less lanes read
+    const int lane_dn = (lane - G.t1 + 1) & 63, lane_up = (lane + G.t1 - 1) & 63;
+    int l0;
+    long c;
+    // ---- forward: y_c = r_c - sum_lower L_co y_(c+o) ---------------------------------------------------------------
+    {
+        double yh[4][B];                   // this lane's results of steps s-1 .. s-4
+#pragma unroll
+        for (int d = 0; d < 4; ++d)
+#pragma unroll
+            for (int r = 0; r < B; ++r) yh[d][r] = 0.0;
+        struct Buf { double v[NF], rr[B]; bool ok; };
+        Buf buf[2];
+        auto load = [&](Buf &k, int step) {
+            k.ok = tile_cell1(G, ti, step, l0, c);
+            const double *ch = fwd + (chunk0 + step) * (long)(NF * 64) + lane;
+#pragma unroll
+            for (int e = 0; e < NF; ++e) k.v[e] = ch[(long)e * 64];
+            const long cs = k.ok ? c : park;
+#pragma unroll
+            for (int r = 0; r < B; ++r) k.rr[r] = rhs[(long)r * nt + cs];
+        };
+        auto step = [&](const Buf &k, int s) {
+            double yn[6][B], y[B];
+#pragma unroll
+            for (int r = 0; r < B; ++r) {
+                yn[0][r] = __shfl_up(yh[3][r], G.t1, 64);      // (0,0,-1)  step s-4
+                yn[1][r] = __shfl_up(yh[2][r], G.t1, 64);      // (1,0,-1)  step s-3
+                yn[2][r] = __shfl(yh[1][r], lane_dn, 64);      // (0,1,-1)  step s-2
+                yn[3][r] = __shfl_up(yh[1][r], 1, 64);         // (0,-1,0)  step s-2
+                yn[4][r] = __shfl_up(yh[0][r], 1, 64);         // (1,-1,0)  step s-1
+                yn[5][r] = yh[0][r];                           // (-1,0,0)  step s-1
+                y[r] = k.rr[r];
+            }
+#pragma unroll
+            for (int i = 0; i < 6; ++i)            // blocks of couplings that leave the tile are stored as zeros
+#pragma unroll
+                for (int r = 0; r < B; ++r)
+#pragma unroll
+                    for (int q = 0; q < B; ++q) y[r] -= k.v[i * BB + r * B + q] * yn[i][q];
+            double *ych = ytmp + (chunk0 + s) * (long)(B * 64) + lane;
+#pragma unroll
+            for (int r = 0; r < B; ++r) {
+                y[r] = k.ok ? y[r] : 0.0;
+                ych[r * 64] = y[r];
+                yh[3][r] = yh[2][r]; yh[2][r] = yh[1][r]; yh[1][r] = yh[0][r]; yh[0][r] = y[r];
+            }
+        };
+        load(buf[0], 0);
+        for (int s = 0; s < ns; s += 2) {
+            if (s + 1 < ns) load(buf[1], s + 1);
+            step(buf[0], s);
+            if (s + 1 < ns) {
+                if (s + 2 < ns) load(buf[0], s + 2);
+                step(buf[1], s + 1);
+            }
+        }
+    }
+    // ---- backward: x_c = D~_c^-1 (y_c - sum_upper U_co x_(c+o)) ----------------------------------------------------
+    {
+        double xh[4][B];                   // this lane's results of steps s+1 .. s+4
+#pragma unroll
+        for (int d = 0; d < 4; ++d)
+#pragma unroll
+            for (int r = 0; r < B; ++r) xh[d][r] = 0.0;
+        struct Buf { double v[NB], yy[B], aa[B]; bool ok; long c; };
+        Buf buf[2];
+        const double *asrc[B];
+        double amask[B];
+#pragma unroll
+        for (int r = 0; r < B; ++r) {
+            const bool use = addto && r < nadd;
+            asrc[r] = (use ? addto : rhs) + (long)r * nt;
+            amask[r] = use ? 1.0 : 0.0;
+        }
+        auto load = [&](Buf &k, int step) {
+            k.ok = tile_cell1(G, ti, step, l0, c);
+            k.c = k.ok ? c : park;
+            const double *ch = bwd + (chunk0 + step) * (long)(NB * 64) + lane;
+#pragma unroll
+            for (int e = 0; e < NB; ++e) k.v[e] = ch[(long)e * 64];
+            const double *ych = ytmp + (chunk0 + step) * (long)(B * 64) + lane;
+#pragma unroll
+            for (int r = 0; r < B; ++r) {
+                k.yy[r] = ych[r * 64];
+                k.aa[r] = asrc[r][k.c];
+            }
+        };
+        auto step = [&](const Buf &k, int s) {
+            double xn[6][B], t[B], xv[B];
+#pragma unroll
+            for (int r = 0; r < B; ++r) {
+                xn[0][r] = xh[0][r];                           // (1,0,0)   step s+1
+                xn[1][r] = __shfl_down(xh[0][r], 1, 64);       // (-1,1,0)  step s+1
+                xn[2][r] = __shfl_down(xh[1][r], 1, 64);       // (0,1,0)   step s+2
+                xn[3][r] = __shfl(xh[1][r], lane_up, 64);      // (0,-1,1)  step s+2
+                xn[4][r] = __shfl_down(xh[2][r], G.t1, 64);    // (-1,0,1)  step s+3
+                xn[5][r] = __shfl_down(xh[3][r], G.t1, 64);    // (0,0,1)   step s+4
+                t[r] = k.yy[r];
+            }
+#pragma unroll
+            for (int i = 0; i < 6; ++i)
+#pragma unroll
+                for (int r = 0; r < B; ++r)
+#pragma unroll
+                    for (int q = 0; q < B; ++q) t[r] -= k.v[i * BB + r * B + q] * xn[i][q];
+#pragma unroll
+            for (int r = 0; r < B; ++r) {
+                double v = 0.0;
+#pragma unroll
+                for (int q = 0; q < B; ++q) v += k.v[6 * BB + r * B + q] * t[q];
+                xv[r] = k.ok ? v : 0.0;
+            }
+#pragma unroll
+            for (int r = 0; r < B; ++r) {
+                xh[3][r] = xh[2][r]; xh[2][r] = xh[1][r]; xh[1][r] = xh[0][r]; xh[0][r] = xv[r];
+                // lanes without a cell write 0.0 to an entry of x's lower halo plane (as the ILU(0) sweep does)
+                x[(long)r * nt + k.c] = k.ok ? amask[r] * k.aa[r] + xv[r] : 0.0;
+            }
+        };
+        load(buf[0], ns - 1);
+        for (int s = ns - 1; s >= 0; s -= 2) {
+            if (s - 1 >= 0) load(buf[1], s - 1);
+            step(buf[0], s);
+            if (s - 1 >= 0) {
+                if (s - 2 >= 0) load(buf[0], s - 2);
+                step(buf[1], s - 1);
+            }
+        }
+    }
+}
+
 // Rows as wide as the tile (t1*t2 double2) or as wide as the wave (64).  Compact rows save the padding bytes of tiles
 // that do not fill a wave -- what the bandwidth-bound 3-D sweeps need -- but make the row stride a run-time value: the
 // 14-18 loads of a step then need scalar address arithmetic instead of immediate offsets, and the small 2-D
@@ -528,9 +815,19 @@ void ilu_setup(tp_ctx *c) {
     d.nt1 = (g.n1 + t1 - 1) / t1;
     d.nt2 = (g.n2 + t2 - 1) / t2;
     d.ntiles = d.nt0 * d.nt1 * d.nt2;
-    d.nsteps = t0 + t1 + t2 - 2;
+    TP_REQUIRE(c->opt.ilu_levels == 0 || c->opt.ilu_levels == 1, "ilu_levels must be 0 or 1");
+    d.levels = c->opt.ilu_levels;
+    d.nsteps = d.levels ? t0 + 2 * (t1 - 1) + 4 * (t2 - 1) : t0 + t1 + t2 - 2;
     d.slots = (long)d.ntiles * d.nsteps * 64;
     c->graph_epoch++;            // new tile layout / factor buffers: captured pc_apply graphs are stale
+    if (d.levels) {
+        const size_t chunks = (size_t)d.ntiles * d.nsteps, bb = (size_t)c->b * c->b;
+        d.fwd.alloc(chunks * 6 * bb * 64);
+        d.bwd.alloc(chunks * 7 * bb * 64);
+        d.ytmp.alloc(chunks * c->b * 64);
+        d.jt.free();
+        return;
+    }
     if (c->b == 3) alloc_factor<3>(d, ilu_compact(c)); else alloc_factor<2>(d, ilu_compact(c));
 }
 
@@ -538,6 +835,14 @@ void ilu_factor(tp_ctx *c) {
     TP_REQUIRE(c->jac_ready, "Jacobian not assembled");
     if (c->ilu.slots == 0) ilu_setup(c);
     const IluGeom G = geom_of(c);
+    if (c->ilu.levels) {
+        for (int s = 0; s < G.nsteps; ++s) {
+            if (c->b == 3) hipLaunchKernelGGL((k_ilu1_level<3>), dim3(c->ilu.ntiles), dim3(64), 0, c->stream, G, c->J.p, c->ilu.fwd.p, c->ilu.bwd.p, s);
+            else           hipLaunchKernelGGL((k_ilu1_level<2>), dim3(c->ilu.ntiles), dim3(64), 0, c->stream, G, c->J.p, c->ilu.fwd.p, c->ilu.bwd.p, s);
+        }
+        TP_HIP(hipGetLastError());
+        return;
+    }
     const int nseg = (G.nsteps + ILU_SEG - 1) / ILU_SEG;
     const bool cp = ilu_compact(c);
 #define TP_ILU_FACTOR(BB, CC)                                                                                          \
@@ -575,6 +880,12 @@ void ilu_solve(tp_ctx *c, const double *r, double *x, const double *addto, int n
     if (nadd < 0) nadd = c->b;
     TP_REQUIRE(c->ilu.slots > 0, "ILU not factored");
     const IluGeom G = geom_of(c);
+    if (c->ilu.levels) {
+        if (c->b == 3) hipLaunchKernelGGL((k_ilu1_solve<3>), dim3(c->ilu.ntiles), dim3(64), 0, c->stream, G, c->ilu.fwd.p, c->ilu.bwd.p, r, c->ilu.ytmp.p, x, addto, nadd);
+        else           hipLaunchKernelGGL((k_ilu1_solve<2>), dim3(c->ilu.ntiles), dim3(64), 0, c->stream, G, c->ilu.fwd.p, c->ilu.bwd.p, r, c->ilu.ytmp.p, x, addto, nadd);
+        TP_HIP(hipGetLastError());
+        return;
+    }
     static const bool deep = !(getenv("TP_ILU_DEPTH") && atoi(getenv("TP_ILU_DEPTH")) == 1);
     static const bool ylds_on = !(getenv("TP_ILU_YLDS") && atoi(getenv("TP_ILU_YLDS")) == 0);
     // y in LDS when the tile's whole intermediate vector fits one CU's 160 KB (one workgroup per CU then)

@@ -86,7 +86,7 @@ def engine_options(solver_parameters, model_name, decoup="No"):
     o["schur_a11"] = False
     used = set()
     build_keys = ("amg_omega", "amg_nu", "amg_min_cells", "amg_full_levels", "amg_coarse_pre", "amg_coarse_post", "amg_mid_skip", "amg_tail_post", "amg_single",
-                  "amg_gather_cells", "amg_dom_tau", "ilu_tile")
+                  "amg_gather_cells", "amg_dom_tau", "ilu_tile", "ilu_levels")
     for k in build_keys:
         if k in sp:
             o[k] = sp.pop(k)
@@ -146,8 +146,10 @@ def engine_options(solver_parameters, model_name, decoup="No"):
         raise NotImplementedError("pc_composite_pcs missing")
     # stage 2: bjacobi + ILU(0) (singlephase.py:348-349); block count: see engine.tiles_for_blocks
     _take(sp, used, "sub_1_sub_pc_type", ("ilu",))
-    if int(_take(sp, used, "sub_1_sub_pc_factor_levels", None, 0)) != 0:
-        raise NotImplementedError("stage 2 must be ILU(0) (pc_cprilu1_gmres is not on the hot path)")
+    levels = int(_take(sp, used, "sub_1_sub_pc_factor_levels", None, 0))
+    if levels not in (0, 1):
+        raise NotImplementedError("stage 2 is block-ILU(0) or block-ILU(1) (sub_1_sub_pc_factor_levels %d)" % levels)
+    o["ilu_levels"] = levels
     nb = _take(sp, used, "sub_1_pc_bjacobi_blocks")
     if nb is not None:
         o["bjacobi_blocks"] = int(nb)
