@@ -166,8 +166,13 @@ def test_solver_option_mapping_and_rejections():
     assert m5.engine_opts["pc"] == "cpr" and m5.engine_opts["decoup"] == "No"
     m6 = SinglePhase(g, c, p, solver_parameters="pc_cpr_gmres", filename=None, verbosity=False, _engine_factory=OracleEngine)
     assert m6.engine_opts["pc"] == "cpr"
-    with pytest.raises(NotImplementedError):     # ILU(1) second stage
-        engine_options({**m5.solver_parameters, "sub_1_sub_pc_factor_levels": 1}, "Two-phase")
+    # ILU(1) second stage: pc_cprilu1_gmres (twophase.py:653-668); deeper fill is not built
+    assert engine_options({**m5.solver_parameters, "sub_1_sub_pc_factor_levels": 1}, "Two-phase")["ilu_levels"] == 1
+    assert m5.engine_opts["ilu_levels"] == 0
+    m7 = TwoPhase(g, c2, p2, solver_parameters="pc_cprilu1_gmres", filename=None, verbosity=False, _engine_factory=OracleEngine)
+    assert m7.engine_opts["pc"] == "cpr" and m7.engine_opts["ilu_levels"] == 1
+    with pytest.raises(NotImplementedError):
+        engine_options({**m5.solver_parameters, "sub_1_sub_pc_factor_levels": 2}, "Two-phase")
     with pytest.raises(NotImplementedError):
         engine_options({"pc_type": "lu", "ksp_type": "preonly"}, "Single phase")
     with pytest.raises(KeyError):

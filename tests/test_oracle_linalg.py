@@ -152,6 +152,72 @@ def test_tiled_ilu_equals_ilu_of_block_diagonal_restriction():
     assert np.allclose(ilu.solve(r), ref.solve(r), rtol=1e-11, atol=1e-13)
 
 
+def _dense_block_iluk(A, b, lev):
+    """Textbook block ILU(lev): symbolic phase by the level-of-fill rule on the cell graph (lev(i,j) = min over k of
+    lev(i,k) + lev(k,j) + 1), numeric phase = IKJ elimination restricted to that pattern.  Returns (L, U) dense."""
+    n = A.shape[0]//b
+    B = lambda M, i, j: M[i*b:(i + 1)*b, j*b:(j + 1)*b]
+    lv = np.full((n, n), 10**6)
+    for i in range(n):
+        for j in range(n):
+            if i == j or np.any(B(A, i, j) != 0):
+                lv[i, j] = 0
+    for i in range(n):
+        for k in range(i):
+            if lv[i, k] <= lev:
+                for j in range(k + 1, n):
+                    if lv[k, j] <= lev:
+                        lv[i, j] = min(lv[i, j], lv[i, k] + lv[k, j] + 1)
+    P = lv <= lev
+    F = A.copy()
+    for i in range(n):
+        for k in range(i):
+            if P[i, k]:
+                Lik = B(F, i, k) @ np.linalg.inv(B(F, k, k))
+                B(F, i, k)[:] = Lik
+                for j in range(k + 1, n):
+                    if P[i, j] and P[k, j]:
+                        B(F, i, j)[:] -= Lik @ B(F, k, j)
+    L, U = np.eye(n*b), np.zeros((n*b, n*b))
+    for i in range(n):
+        for j in range(n):
+            if P[i, j]:
+                (B(L, i, j) if j < i else B(U, i, j))[:] = B(F, i, j)
+    return L, U, P
+
+
+@pytest.mark.parametrize("shape,tile,b", [((3, 4, 5), None, 3), ((1, 5, 6), None, 3), ((2, 2, 7), None, 2),
+                                          ((5, 7, 6), (4, 3, 2), 2)])
+def test_ilu1_is_level_of_fill_one(shape, tile, b):
+    """TiledILU1 (sub_1_sub_pc_factor_levels 1, twophase.py:665-666): its fixed 13-offset pattern and sweep order give the
+    textbook level-of-fill ILU(1) of every tile's diagonal block in natural order (and TiledILU0 gives ILU(0))."""
+    rng = np.random.default_rng(0)
+    n2, n1, n0 = shape
+    J = rng.standard_normal((7, b, b) + shape)*0.3
+    J[0] += 4*np.eye(b)[:, :, None, None, None]
+
+    def cut(M):
+        M[1][..., 0] = 0; M[2][..., -1] = 0; M[3][..., 0, :] = 0; M[4][..., -1, :] = 0; M[5][..., 0, :, :] = 0; M[6][..., -1, :, :] = 0
+        return M
+    cut(J)
+    big = (1 << 30,)*3
+    t = tile or big
+    r = rng.standard_normal((b,) + shape)
+    for lev, cls in ((0, la.TiledILU0), (1, la.TiledILU1)):
+        x = cls(shape, t).factor(J).solve(r)
+        for k0 in range(0, n2, min(t[2], n2)):
+            for j0 in range(0, n1, min(t[1], n1)):
+                for i0 in range(0, n0, min(t[0], n0)):
+                    sl = (slice(k0, min(k0 + t[2], n2)), slice(j0, min(j0 + t[1], n1)), slice(i0, min(i0 + t[0], n0)))
+                    Jt = cut(J[(slice(None),)*3 + sl].copy())
+                    L, U, P = _dense_block_iluk(la.to_csr(Jt).toarray(), b, lev)
+                    rt = r[(slice(None),) + sl]
+                    xd = np.linalg.solve(U, np.linalg.solve(L, rt.reshape(b, -1).T.reshape(-1))).reshape(-1, b).T.reshape(rt.shape)
+                    assert np.abs(x[(slice(None),) + sl] - xd).max() < 1e-13
+    if tile is None and n2 > 2 and n1 > 2 and n0 > 2:
+        assert P.sum(axis=1).max() == 13           # interior rows: 7 stencil entries + 6 level-1 fill entries
+
+
 def test_amg_vcycle_is_a_convergent_preconditioner():
     spec, o = setup_case(builder=cases.c3_spe10_2d, Nx=24, Ny=31, nphase=2)
     J = o.jacobian()
