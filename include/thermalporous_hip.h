@@ -87,9 +87,12 @@ typedef struct tp_options {
     int32_t amg_tail_post;   /* post-sweeps on the levels of <= 1024 cells (they run inside one workgroup, where a
                                 sweep costs ~2 us: small grids live entirely there and want the stronger cycle) */
     int32_t amg_single;      /* 1: AMG operators/weights stored in fp32 (vectors and arithmetic stay fp64) */
-    int32_t schur_a11;       /* pc_kind 1/2: precondition the Schur complement with A_11 (the T-T block, after
-                                decoupling) instead of the convection-diffusion operator S~
-                                (pc_fieldsplit_schur_precondition a11: pc_fieldsplit_a11, pc_cptr_a11) */
+    int32_t schur_a11;       /* what preconditions the Schur complement of pc_kind 1/2 (pc_fieldsplit_schur_precondition):
+                                0 = the convection-diffusion operator S~ (ConvDiffSchurPC / ConvDiffSchurTwoPhasesPC);
+                                1 = a11: A_11, the T-T block after decoupling (pc_fieldsplit_a11, pc_cptr_a11);
+                                2 = selfp (pc_kind 2, one GPU): Sp = A11 - A10 diag(A00)^-1 A01 (pc_fieldsplit_selfp,
+                                    singlephase.py:322-330): V-cycle of the hierarchy of Sp's 7-point collapse (far
+                                    entries lumped onto the diagonal) + one damped-Jacobi sweep on the exact Sp */
     int32_t amg_gather_cells;/* multi-GPU: AMG levels with more cells than this stay distributed over the slabs
                                 (halo exchange per sweep); smaller ones are gathered and replicated on every
                                 rank.  < 0: replicate the whole hierarchy.  Ignored on one GPU. */

@@ -117,7 +117,7 @@ class CPortEngine:
                         o["snes_rtol"], o["snes_atol"], o["snes_stol"], o["snes_max_it"], o["amg_omega"], o["amg_nu"],
                         o["amg_min_cells"], int(o.get("amg_full_levels", 99)), neg(o.get("amg_coarse_pre")),
                         neg(o.get("amg_coarse_post")), int(bool(o.get("amg_mid_skip", False))), neg(o.get("amg_tail_post")),
-                        int(bool(o.get("amg_single", False))), int(bool(o.get("schur_a11", False))), (C.c_int32*3)(*t),
+                        int(bool(o.get("amg_single", False))), 2 if o.get("schur_selfp") else int(bool(o.get("schur_a11", False))), (C.c_int32*3)(*t),
                         int(o.get("nslabs", 1)), float(o.get("amg_dom_tau", 0.0)), int(o.get("ilu_levels", 0)))
         prm = np.array([float(spec["prm"][k]) for k in _PRM])
         kT = spec.get("kT")

@@ -513,6 +513,7 @@ struct Ctx {
     vec Dinv, Bf, Cb;                                 // D~^-1 ; B_cm = A_cm D~_m^-1 (3/cell) ; C_cm = D~_c^-1 A_up (3/cell)
     // AMG
     SemiAMG amg_p, amg_T;
+    vec sp_S7, sp_invd, sp_d00inv, sp_u, sp_v;         // selfp (oracle.linalg.SelfpSchur): collapse of Sp, w/diag(Sp), 1/diag(A00)
     bool amg_ready = false;
     // work
     vec w_r0, w_r1, w_t, w_y0, w_y1, w_res, w_il, w_yt;
@@ -1174,6 +1175,52 @@ static SView blk(const Ctx &C, int i, int j) {
     return v;
 }
 
+// Sp = A11 - A10 diag(A00)^-1 A01 (pc_fieldsplit_schur_precondition selfp): exact diagonal and 7-point collapse
+// (oracle.linalg.SelfpSchur.setup; same order of operations)
+static void selfp_build(Ctx &C) {
+    const long N = C.g.N;
+    const int n[3] = {C.g.n[0], C.g.n[1], C.g.n[2]};
+    const SView A00 = blk(C, 0, 0), A01 = blk(C, 0, 1), A10 = blk(C, 1, 0), A11 = blk(C, 1, 1);
+    C.sp_S7.assign((size_t)7 * N, 0.0);
+    C.sp_invd.assign(N, 0.0); C.sp_d00inv.assign(N, 0.0); C.sp_u.assign(N, 0.0); C.sp_v.assign(N, 0.0);
+#pragma omp parallel for schedule(static)
+    for (long c = 0; c < N; ++c) C.sp_d00inv[c] = 1.0 / A00.at(0, c);
+#pragma omp parallel for collapse(2) schedule(static)
+    for (int i2 = 0; i2 < n[2]; ++i2)
+        for (int i1 = 0; i1 < n[1]; ++i1)
+            for (int i0 = 0; i0 < n[0]; ++i0) {
+                const long c = i0 + (long)n[0] * (i1 + (long)n[1] * i2);
+                const int I[3] = {i0, i1, i2};
+                double S[7];
+                for (int s = 0; s < 7; ++s) S[s] = A11.at(s, c);
+                const double t0 = A10.at(0, c) * C.sp_d00inv[c];
+                S[0] -= t0 * A01.at(0, c);
+                double lump = 0.0;
+                for (int s = 1; s < 7; ++s) {
+                    const int a = (s - 1) / 2;
+                    const bool odd = s % 2 == 1;
+                    if (n[a] == 1 || (odd ? I[a] == 0 : I[a] + 1 >= n[a])) continue;      // no neighbour m in direction s
+                    const long m = c + (odd ? -C.g.st[a] : C.g.st[a]);
+                    const int opp = odd ? s + 1 : s - 1;
+                    S[s] -= t0 * A01.at(s, c);
+                    const double w = A10.at(s, c) * C.sp_d00inv[m];
+                    S[s] -= w * A01.at(0, m);
+                    S[0] -= w * A01.at(opp, m);
+                    int Im[3] = {i0, i1, i2};
+                    Im[a] += odd ? -1 : 1;
+                    for (int t = 1; t < 7; ++t) {
+                        const int at = (t - 1) / 2;
+                        if (t == opp || n[at] == 1) continue;
+                        if (t % 2 == 1 ? Im[at] == 0 : Im[at] + 1 >= n[at]) continue;    // m has no neighbour in direction t
+                        lump -= w * A01.at(t, m);
+                    }
+                }
+                C.sp_invd[c] = C.o.amg_omega / S[0];
+                S[0] += lump;
+                for (int s = 0; s < 7; ++s) C.sp_S7[(size_t)c * 7 + s] = S[s];
+            }
+}
+
 static void pc_setup(Ctx &C) {
     const long N = C.g.N;
     const int b = C.b;
@@ -1229,7 +1276,8 @@ static void pc_setup(Ctx &C) {
     C.amg_p.setup(blk(C, 0, 0));
     if (C.o.pc >= 1) {
         SView S;
-        if (C.o.schur_a11) S = blk(C, 1, 1);
+        if (C.o.schur_a11 == 2) { selfp_build(C); S.base = C.sp_S7.data(); S.cs = 7; S.ss = 1; }
+        else if (C.o.schur_a11) S = blk(C, 1, 1);
         else { S.base = C.Sm.data(); S.cs = 7; S.ss = 1; }
         C.amg_T.setup(S);
     }
@@ -1273,6 +1321,16 @@ static void stage1(Ctx &C, const double *x, double *y) {      // TwoStagePC.stag
 #pragma omp parallel for schedule(static)
     for (long c = 0; c < N; ++c) t[c] = r1[c] - t[c];
     C.amg_T.vcycle(t, y + N);
+    if (C.o.schur_a11 == 2) {          // selfp: x += w D^-1 (b - Sp x) with the exact Sp = A11 - A10 diag(A00)^-1 A01
+        double *x1 = y + N, *u = C.sp_u.data(), *v = C.sp_v.data();
+        spmv_scalar(C.g, A01, x1, u);
+#pragma omp parallel for schedule(static)
+        for (long c = 0; c < N; ++c) u[c] *= C.sp_d00inv[c];
+        spmv_scalar(C.g, A10, u, v);
+        spmv_scalar(C.g, blk(C, 1, 1), x1, u);
+#pragma omp parallel for schedule(static)
+        for (long c = 0; c < N; ++c) x1[c] += C.sp_invd[c] * (t[c] - (u[c] - v[c]));
+    }
     spmv_scalar(C.g, A01, y + N, t);
 #pragma omp parallel for schedule(static)
     for (long c = 0; c < N; ++c) t[c] = r0[c] - t[c];

@@ -622,6 +622,65 @@ def _decouple_temp(J, kind, primary):
     return At, [(dT, dS)]
 
 
+class SelfpSchur:
+    """K(S) for pc_fieldsplit_schur_precondition selfp (pc_fieldsplit_selfp, singlephase.py:322-330): one V-cycle on
+    Sp = A11 - A10 diag(A00)^-1 A01, which PETSc forms explicitly (a 13-point operator in 2-D, 25-point in 3-D).
+
+    Here the hierarchy is the 7-point semicoarsening AMG of Sp's collapse S7 -- the 7-point entries of Sp exactly, the far
+    entries (c -> m -> j with j neither c nor a stencil neighbour of c) lumped onto the diagonal (row sums preserved) --
+    followed by one damped-Jacobi sweep on the EXACT Sp, applied matrix-free (three 7-point products and a diagonal
+    scaling) with its exact diagonal D:
+        x = V7(b) ;  x += w D^-1 (b - Sp x).
+    (Sp is indefinite on hard states -- diag(A00)^-1 is a poor stand-in for A00^-1 near wells at large dt -- and a
+    pre-smoothing sweep from the zero guess, x = w D^-1 b, then makes FGMRES stall; measured on C2-like cases, where
+    this form stays within 10 % of an exact Sp solve.)"""
+
+    def __init__(self, amg, omega):
+        self.amg, self.omega = amg, omega
+
+    def setup(self, A00, A01, A10, A11):
+        shape = A00.shape[1:]
+        dinv = 1.0/A00[0]
+        S7 = A11.copy()
+        t0 = A10[0]*dinv
+        S7[0] -= t0*A01[0]
+        lump = np.zeros(shape)
+        for s in range(1, 7):
+            a = (s - 1)//2
+            if shape[2 - a] == 1:
+                continue
+            odd = s % 2 == 1                              # odd slots look down the axis: cells _hi have that neighbour
+            sc, sm = (_hi(a), _lo(a)) if odd else (_lo(a), _hi(a))
+            opp = s + 1 if odd else s - 1
+            S7[s][sc] -= t0[sc]*A01[s][sc]                 # c -> c -> m
+            w = A10[s][sc]*dinv[sm]                        # c -> m
+            S7[s][sc] -= w*A01[0][sm]                      # c -> m -> m
+            S7[0][sc] -= w*A01[opp][sm]                    # c -> m -> c
+            for t in range(1, 7):
+                at = (t - 1)//2
+                if t == opp or shape[2 - at] == 1:
+                    continue
+                # m's own boundary entries are zero by assembly; mask them anyway through the validity of m + off_t
+                ok = np.zeros(shape, dtype=bool)
+                ok[_hi(at) if t % 2 == 1 else _lo(at)] = True
+                lump[sc] -= np.where(ok[sm], w*A01[t][sm], 0.0)
+        self.diag = S7[0].copy()                           # diag(Sp), exact
+        S7[0] += lump
+        self.S7 = S7
+        self.ops = (A01, A10, A11, dinv)
+        self.invd = self.omega/self.diag
+        self.amg.setup(S7)
+        return self
+
+    def mult(self, x):
+        A01, A10, A11, dinv = self.ops
+        return spmv_scalar(A11, x) - spmv_scalar(A10, dinv*spmv_scalar(A01, x))
+
+    def vcycle(self, b):
+        x = self.amg.vcycle(b)
+        return x + self.invd*(b - self.mult(x))
+
+
 def slab_ranges(n2, nslabs):
     """Planes [lo, hi) of internal axis 2 per slab (same rule as thermalporous_amd.engine.slab_range)."""
     base, rem = divmod(n2, nslabs)
@@ -690,7 +749,12 @@ class TwoStagePC:
             assert J.shape[1] == 2 and o["decoup"] == "No"
             self.At, self.d = decouple(J, "No", [0, 1])
             self.amg_p.setup(self.At[:, 0, 0])
-            self.amg_T.setup(self.At[:, 1, 1] if o.get("schur_a11") else Sm)     # (singlephase.py:331-338: a11)
+            if o.get("schur_selfp"):                       # (singlephase.py:322-330: selfp)
+                At = self.At
+                self.selfp = SelfpSchur(self.amg_T, o["amg_omega"]).setup(At[:, 0, 0], At[:, 0, 1], At[:, 1, 0], At[:, 1, 1])
+            else:
+                self.selfp = None
+                self.amg_T.setup(self.At[:, 1, 1] if o.get("schur_a11") else Sm)     # (singlephase.py:331-338: a11)
         else:
             raise ValueError(o["pc"])
 
@@ -718,7 +782,8 @@ class TwoStagePC:
             At = self.At
             # PCFIELDSPLIT schur FULL: y0 = K(A00) r0; y1 = K(S)(r1 - A10 y0); y0 = K(A00)(r0 - A01 y1)
             y0 = self.amg_p.vcycle(r0)
-            y1 = self.amg_T.vcycle(r1 - spmv_scalar(At[:, 1, 0], y0))
+            KS = self.selfp.vcycle if getattr(self, "selfp", None) is not None else self.amg_T.vcycle
+            y1 = KS(r1 - spmv_scalar(At[:, 1, 0], y0))
             y0 = self.amg_p.vcycle(r0 - spmv_scalar(At[:, 0, 1], y1))
             y[0], y[1] = y0, y1
             self.vcycles += 3

@@ -114,6 +114,44 @@ def test_fieldsplit_cd_preset_and_pc_classes():
     h.close()
 
 
+@pytest.mark.parametrize("preset", ["pc_fieldsplit_selfp", "pc_fieldsplit_a11"])
+def test_single_phase_schur_presets_time_loop(preset):
+    """pc_fieldsplit_selfp (singlephase.py:322-330) and pc_fieldsplit_a11 (:331-338) through SinglePhase.solve() on the
+    SPE10-like 2-D case: HIP engine vs oracle engine, same Newton counts, Krylov counts +-1, same converged state."""
+    from oracle.engine import OracleEngine
+    from thermalporous_amd.singlephase import SinglePhase
+    res = []
+    for factory in (OracleEngine, None):
+        spec, u0, p, g, c = cases.c3_spe10_2d(Nx=14, Ny=19, nphase=1)
+        m = SinglePhase(g, c, p, end=0.5, maxdt=0.25, small_dt_start=False, solver_parameters=preset, filename=None,
+                        verbosity=False, _engine_factory=factory)
+        assert m.engine_opts["schur_selfp"] == (preset == "pc_fieldsplit_selfp")
+        m.solve()
+        res.append((m.nits_vec, m.lits_vec, m.u.dat.data_ro[0].copy(), m.u.dat.data_ro[1].copy()))
+    assert res[0][0] == res[1][0] and len(res[0][0]) >= 2
+    assert all(abs(a - b) <= 1 for a, b in zip(res[0][1], res[1][1]))
+    assert rel2(res[1][2], res[0][2]) < 1e-8 and rel2(res[1][3], res[0][3]) < 1e-8
+
+
+def test_two_phase_ilu1_preset_time_loop():
+    """pc_cprilu1_gmres (twophase.py:653-668: CPR stage 1 + block-ILU(1) second stage) through TwoPhase.solve():
+    HIP engine vs oracle engine."""
+    from oracle.engine import OracleEngine
+    from thermalporous_amd.twophase import TwoPhase
+    res = []
+    for factory in (OracleEngine, None):
+        spec, u0, p, g, c = cases.c4_spe10_3d(Nx=7, Ny=13, Nz=9, nphase=2)
+        m = TwoPhase(g, c, p, end=0.02, maxdt=0.01, small_dt_start=False, solver_parameters="pc_cprilu1_gmres",
+                     filename=None, verbosity=False, _engine_factory=factory)
+        assert m.engine_opts["ilu_levels"] == 1 and m.engine_opts["pc"] == "cpr"
+        m.solve()
+        res.append((m.nits_vec, m.lits_vec, [d.copy() for d in m.u.dat.data_ro]))
+    assert res[0][0] == res[1][0] and len(res[0][0]) >= 2
+    assert all(abs(a - b) <= 1 for a, b in zip(res[0][1], res[1][1]))
+    for a, b in zip(res[1][2], res[0][2]):
+        assert rel2(a, b) < 1e-7
+
+
 def test_full_size_properties_c4():
     """BASELINE config 4 at full size (60x220x85): size-independent properties of the GPU path --
     pairwise cancellation of the face fluxes, linearity of every preconditioner stage, and the true

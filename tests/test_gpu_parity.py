@@ -59,6 +59,10 @@ CASES = [
     ("c4_2ph_3d_cptramg_QI", cases.c4_spe10_3d, dict(Nx=9, Ny=14, Nz=8, nphase=2), dict(pc="cptramg", decoup="QI")),
     ("c4_2ph_3d_cptramg_TI", cases.c4_spe10_3d, dict(Nx=16, Ny=18, Nz=16, nphase=2), dict(pc="cptramg", decoup="TI", amg_full_levels=1)),
     ("c3_2ph_2d_cptramg", cases.c3_spe10_2d, dict(Nx=14, Ny=19, nphase=2), dict(pc="cptramg", decoup="QI", ilu_tile=(1 << 30, 64, 1))),
+    # pc_fieldsplit_selfp (singlephase.py:322-330): Sp = A11 - A10 diag(A00)^-1 A01 preconditions the Schur complement
+    ("c4_1ph_3d_selfp", cases.c4_spe10_3d, dict(Nx=7, Ny=13, Nz=9, nphase=1), dict(pc="fieldsplit_cd", schur_selfp=True)),
+    ("c2_1ph_2d_selfp", cases.c3_spe10_2d, dict(Nx=14, Ny=19, nphase=1), dict(pc="fieldsplit_cd", schur_selfp=True)),
+    ("c1_1ph_2d_selfp", cases.c1_homogeneous, dict(N=12, nphase=1), dict(pc="fieldsplit_cd", schur_selfp=True)),
     # block-ILU(1) second stage (pc_cprilu1_gmres, twophase.py:653-668): partial tiles, whole-line tiles, 2-D, 2x2 blocks
     ("c4_2ph_3d_ilu1_tiles", cases.c4_spe10_3d, dict(Nx=11, Ny=13, Nz=17, nphase=2), dict(pc="cpr", ilu_levels=1, ilu_tile=(5, 4, 7))),
     ("c4_2ph_3d_cptr_ilu1", cases.c4_spe10_3d, dict(Nx=9, Ny=14, Nz=8, nphase=2), dict(pc="cptr", ilu_levels=1)),

@@ -141,13 +141,15 @@ def test_solver_option_mapping_and_rejections():
     m3 = SinglePhase(g, c, p, solver_parameters="pc_fieldsplit_cd", filename=None, verbosity=False,
                      _engine_factory=OracleEngine)
     assert m3.engine_opts["pc"] == "fieldsplit_cd" and m3.engine_opts["decoup"] == "No"
-    with pytest.raises(NotImplementedError):     # selfp / a11 Schur preconditioning are not on the path
+    with pytest.raises(NotImplementedError):     # other Schur preconditioners (self, full, user) are not on the path
         engine_options({"pc_type": "fieldsplit", "pc_fieldsplit_type": "schur", "pc_fieldsplit_schur_fact_type": "FULL",
-                        "pc_fieldsplit_schur_precondition": "selfp"}, "Single phase")
+                        "pc_fieldsplit_schur_precondition": "self"}, "Single phase")
     with pytest.raises(NotImplementedError):     # the single-phase block PC does not exist for two phases
         engine_options(m3.solver_parameters, "Two-phase")
-    with pytest.raises(NotImplementedError):
-        SinglePhase(g, c, p, solver_parameters="pc_fieldsplit_selfp", filename=None, _engine_factory=OracleEngine)
+    m3s = SinglePhase(g, c, p, solver_parameters="pc_fieldsplit_selfp", filename=None, verbosity=False,       # (:322-330)
+                      _engine_factory=OracleEngine)
+    assert m3s.engine_opts["pc"] == "fieldsplit_cd" and m3s.engine_opts["schur_selfp"] is True and m3s.engine_opts["schur_a11"] is False
+    assert m3.engine_opts["schur_selfp"] is False
     m7 = SinglePhase(g, c, p, solver_parameters="pc_fieldsplit_a11", filename=None, verbosity=False, _engine_factory=OracleEngine)
     assert m7.engine_opts["pc"] == "fieldsplit_cd" and m7.engine_opts["schur_a11"] is True and m3.engine_opts["schur_a11"] is False
     m8 = TwoPhase(g, WellCase(p2, g, well_case="test0", constant_rate=True), p2, solver_parameters="pc_cptr_a11", filename=None,

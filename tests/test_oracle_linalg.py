@@ -218,6 +218,46 @@ def test_ilu1_is_level_of_fill_one(shape, tile, b):
         assert P.sum(axis=1).max() == 13           # interior rows: 7 stencil entries + 6 level-1 fill entries
 
 
+@pytest.mark.parametrize("builder,kw", [(cases.c4_spe10_3d, dict(Nx=7, Ny=9, Nz=6, nphase=1)),
+                                        (cases.c3_spe10_2d, dict(Nx=14, Ny=19, nphase=1))])
+def test_selfp_operator_is_the_explicit_sparse_product(builder, kw):
+    """SelfpSchur (pc_fieldsplit_schur_precondition selfp, singlephase.py:322-330) against PETSc's definition
+    Sp = A11 - A10 diag(A00)^-1 A01 formed explicitly with scipy: the matrix-free product and the diagonal are exact,
+    the 7-point collapse keeps the 7-point entries and the row sums of Sp, and the resulting preconditioner is as good
+    as an exact Sp solve to within a few Krylov iterations."""
+    import scipy.sparse as sp
+    import scipy.sparse.linalg as spl
+    from oracle.engine import OracleEngine
+    spec, u0, *_ = builder(**kw)
+    o = OracleEngine(spec, dict(pc="fieldsplit_cd", ksp_rtol=1e-8, schur_selfp=True))
+    o.set_old(u0)
+    o.set_dt(8640.0)
+    o.set_state(cases.perturbed_state(spec, seed=5, amp=0.3))
+    J, Sm = o.jacobian(want_schur=True)
+    o.pc.setup(J, Sm)
+    shape = J.shape[3:]
+    n = int(np.prod(shape))
+    csr = lambda A: la.to_csr(A[:, None, None])
+    A00, A01, A10, A11 = (csr(o.pc.At[:, i, j]) for i, j in ((0, 0), (0, 1), (1, 0), (1, 1)))
+    Sp = (A11 - A10 @ sp.diags(1.0/A00.diagonal()) @ A01).tocsc()
+    sel = o.pc.selfp
+    x = np.random.default_rng(0).standard_normal(shape)
+    d = np.abs(Sp.diagonal()).max()
+    assert np.abs(sel.mult(x).ravel() - Sp @ x.ravel()).max() < 1e-13*np.abs(Sp @ x.ravel()).max()
+    assert np.abs(sel.diag.ravel() - Sp.diagonal()).max() < 1e-13*d
+    S7 = csr(sel.S7)
+    assert np.abs(np.asarray(S7.sum(axis=1)).ravel() - np.asarray(Sp.sum(axis=1)).ravel()).max() < 1e-12*d
+    offd = (abs(S7) > 0).astype(float) - sp.eye(n)
+    assert abs(Sp.multiply(offd) - S7.multiply(offd)).max() < 1e-13*d
+    assert Sp.nnz > S7.nnz                                      # (13- / 25-point vs 5- / 7-point)
+    F = o.residual()
+    mv = lambda v: la.spmv_block(J, v)
+    _, its, reason, _ = la.fgmres(mv, o.pc.apply, F, rtol=1e-8)
+    o.pc.selfp = type("Exact", (), {"vcycle": staticmethod(lambda b: spl.spsolve(Sp, b.ravel()).reshape(shape))})()
+    _, its_x, reason_x, _ = la.fgmres(mv, o.pc.apply, F, rtol=1e-8)
+    assert reason == reason_x == 2 and its <= its_x + 2, (its, its_x)
+
+
 def test_amg_vcycle_is_a_convergent_preconditioner():
     spec, o = setup_case(builder=cases.c3_spe10_2d, Nx=24, Ny=31, nphase=2)
     J = o.jacobian()

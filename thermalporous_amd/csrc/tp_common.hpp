@@ -211,6 +211,7 @@ struct tp_ctx {
     tp::Stencil opA00, opA01, opA10;   // views used by stage 1
     tp::Amg *amg_p = nullptr, *amg_T = nullptr;
     tp::BAmg *bamg = nullptr;          // pc_cptramg: system AMG on the (p,T) blocks (tp_amg_block.hip)
+    tp::DBuf<double> spbuf;            // selfp (schur_a11 == 2): S7 (7 planes), w/diag(Sp), two work planes
     tp::DBuf<double> gAt;              // multi-GPU pc_cptramg: the 28 operator planes gathered on the global grid
     tp::IluData ilu;
     // FGMRES workspace
@@ -267,6 +268,8 @@ void spmv_block(tp_ctx *c, const double *J, const double *x, double *y);        
 void resid_block_cols(tp_ctx *c, const double *J, const double *x, const double *y, int ncols, double *r);  // r = x - J[:, :ncols] y
 void spmv_scalar(tp_ctx *c, const GridDev &g, const Stencil &A, const double *x, double *y, double alpha, const double *z);  // y = z + alpha*A x (z may be null)
 void decouple(tp_ctx *c);
+void selfp_build(tp_ctx *c);                                                           // S7, w/diag(Sp) into spbuf
+void selfp_post(tp_ctx *c, const double *b, const double *x, double *y);                  // y = x + w D^-1 (b - Sp x)
 void stage1_rhs(tp_ctx *c, const double *x, int q, double *out);                        // out = x_q - d_q x_s
 // ILU
 void ilu_setup(tp_ctx *c);

@@ -427,6 +427,105 @@ void spmv_scalar(tp_ctx *c, const GridDev &g, const Stencil &A, const double *x,
     TP_HIP(hipGetLastError());
 }
 
+// ---- selfp: Sp = A11 - A10 diag(A00)^-1 A01 (pc_fieldsplit_schur_precondition selfp, singlephase.py:322-330) ------
+// PETSc forms Sp explicitly (13-point in 2-D, 25-point in 3-D).  Here (oracle/linalg.py:SelfpSchur): the AMG hierarchy
+// is that of Sp's 7-point collapse S7 -- the 7-point entries of Sp exactly, the far entries (c -> m -> j, j neither c nor
+// a stencil neighbour of c) lumped onto the diagonal -- and one damped-Jacobi sweep on the EXACT Sp follows the V-cycle,
+// matrix-free: x += w D^-1 (b - A11 x + A10 (diag(A00)^-1 (A01 x))), D = diag(Sp) exactly.
+__global__ __launch_bounds__(256) void k_selfp_build(GridDev g, Stencil A00, Stencil A01, Stencil A10, Stencil A11,
+                                                     double omega, double *__restrict__ S7, double *__restrict__ invd) {
+    const long tid = (long)blockIdx.x * blockDim.x + threadIdx.x;
+    if (tid >= g.nown) return;
+    const long c = g.np + tid, nt = g.ntot;
+    const int n[3] = {g.n0, g.n1, g.n2};
+    const int I[3] = {(int)(tid % g.n0), (int)((tid / g.n0) % g.n1), (int)(tid / g.np)};
+    const long off[7] = {0, -1, 1, -(long)g.n0, (long)g.n0, -g.np, g.np};
+    double S[7];
+#pragma unroll
+    for (int s = 0; s < 7; ++s) S[s] = A11.slot(s)[c];
+    const double t0 = A10.slot(0)[c] * (1.0 / A00.slot(0)[c]);
+    S[0] -= t0 * A01.slot(0)[c];
+    double lump = 0.0;
+#pragma unroll
+    for (int s = 1; s < 7; ++s) {
+        const int a = (s - 1) / 2;
+        const bool odd = s & 1;
+        if (n[a] == 1 || (odd ? I[a] == 0 : I[a] + 1 >= n[a])) continue;          // no neighbour m in direction s
+        const long m = c + off[s];
+        const int opp = odd ? s + 1 : s - 1;
+        S[s] -= t0 * A01.slot(s)[c];                                               // c -> c -> m
+        const double w = A10.slot(s)[c] * (1.0 / A00.slot(0)[m]);                  // c -> m
+        S[s] -= w * A01.slot(0)[m];                                                // c -> m -> m
+        S[0] -= w * A01.slot(opp)[m];                                              // c -> m -> c
+#pragma unroll
+        for (int t = 1; t < 7; ++t) {
+            const int at = (t - 1) / 2;
+            if (t == opp || n[at] == 1) continue;
+            const int im = I[at] + (at == a ? (odd ? -1 : 1) : 0);
+            if ((t & 1) ? im == 0 : im + 1 >= n[at]) continue;                    // m has no neighbour in direction t
+            lump -= w * A01.slot(t)[m];                                            // c -> m -> far cell: lumped
+        }
+    }
+    invd[c] = omega / S[0];
+    S[0] += lump;
+#pragma unroll
+    for (int s = 0; s < 7; ++s) S7[(long)s * nt + c] = S[s];
+}
+
+// u = diag(A00)^-1 (A01 x)
+__global__ __launch_bounds__(256) void k_selfp_u(GridDev g, Stencil A00, Stencil A01, const double *__restrict__ x,
+                                                 double *__restrict__ u) {
+    const long tid = xcd_tid();
+    if (tid >= g.nown) return;
+    const long c = g.np + tid;
+    const long off[7] = {0, -1, 1, -(long)g.n0, (long)g.n0, -g.np, g.np};
+    double s = 0.0;
+#pragma unroll
+    for (int k = 0; k < 7; ++k) s += A01.slot(k)[c] * x[c + off[k]];
+    u[c] = s * (1.0 / A00.slot(0)[c]);
+}
+
+// y = x + invd (b - (A11 x - A10 u))
+__global__ __launch_bounds__(256) void k_selfp_post(GridDev g, Stencil A10, Stencil A11, const double *__restrict__ invd,
+                                                    const double *__restrict__ b, const double *__restrict__ x,
+                                                    const double *__restrict__ u, double *__restrict__ y) {
+    const long tid = xcd_tid();
+    if (tid >= g.nown) return;
+    const long c = g.np + tid;
+    const long off[7] = {0, -1, 1, -(long)g.n0, (long)g.n0, -g.np, g.np};
+    double s11 = 0.0, s10 = 0.0;
+#pragma unroll
+    for (int k = 0; k < 7; ++k) {
+        s11 += A11.slot(k)[c] * x[c + off[k]];
+        s10 += A10.slot(k)[c] * u[c + off[k]];
+    }
+    y[c] = x[c] + invd[c] * (b[c] - (s11 - s10));
+}
+
+static Stencil selfp_a11(const tp_ctx *c) {          // the T-T block of the undecoupled single-phase Jacobian
+    Stencil A;
+    A.base = c->J.p + (long)(c->b + 1) * c->g.ntot;
+    A.slot_stride = c->opA00.slot_stride;
+    return A;
+}
+
+void selfp_build(tp_ctx *c) {
+    const GridDev &g = c->g;
+    if (c->spbuf.n < (size_t)10 * g.ntot) c->spbuf.alloc((size_t)10 * g.ntot);     // S7 (7), invd, u, x
+    hipLaunchKernelGGL(k_selfp_build, dim3((unsigned)((g.nown + 255) / 256)), dim3(256), 0, c->stream, g, c->opA00, c->opA01,
+                       c->opA10, selfp_a11(c), c->opt.amg_omega, c->spbuf.p, c->spbuf.p + 7 * g.ntot);
+    TP_HIP(hipGetLastError());
+}
+
+// y = x + w D^-1 (b - Sp x)
+void selfp_post(tp_ctx *c, const double *b, const double *x, double *y) {
+    const GridDev &g = c->g;
+    double *invd = c->spbuf.p + 7 * g.ntot, *u = c->spbuf.p + 8 * g.ntot;
+    hipLaunchKernelGGL(k_selfp_u, xcd_grid(g.nown), dim3(256), 0, c->stream, g, c->opA00, c->opA01, x, u);
+    hipLaunchKernelGGL(k_selfp_post, xcd_grid(g.nown), dim3(256), 0, c->stream, g, c->opA10, selfp_a11(c), invd, b, x, u, y);
+    TP_HIP(hipGetLastError());
+}
+
 // ---- Quasi-/True-IMPES decoupling (preconditioners.py:684-711,785-808,1445-1543) -------------------
 // At[slot][i][j] = J[slot][q_i][q_j] - d_i * J[slot][s][q_j],  d_i = D_{q_i s} / D_ss per cell,
 // D = diagonal entries (QI) or column sums (TI).  A per-cell row operation: no SpGEMM.

@@ -63,7 +63,7 @@ static void face_strengths(tp_ctx *c, double st[3]) {
 static void refresh_pc_signature(tp_ctx *c) {
     const uintptr_t sig[] = {(uintptr_t)c->opA00.base, (uintptr_t)c->opA01.base, (uintptr_t)c->opA10.base,
                              (uintptr_t)c->Sm.p, (uintptr_t)c->ilu.fwd.p, (uintptr_t)c->amg_p, (uintptr_t)c->amg_T, (uintptr_t)c->bamg,
-                             (uintptr_t)c->w1.p, (uintptr_t)c->w3.p, (uintptr_t)c->w4.p, (uintptr_t)c->dcoef.p,
+                             (uintptr_t)c->w1.p, (uintptr_t)c->w3.p, (uintptr_t)c->w4.p, (uintptr_t)c->dcoef.p, (uintptr_t)c->spbuf.p,
                              (uintptr_t)c->opt.amg_nu, (uintptr_t)c->opt.pc_kind, (uintptr_t)c->opt.decoup,
                              (uintptr_t)c->opt.amg_single, (uintptr_t)c->opt.amg_gather_cells, (uintptr_t)c->opt.schur_a11, (uintptr_t)c->opt.amg_full_levels, (uintptr_t)c->opt.amg_coarse_pre, (uintptr_t)c->opt.amg_coarse_post, (uintptr_t)c->opt.amg_tail_post, (uintptr_t)c->opt.amg_mid_skip,
                              (uintptr_t)c->ilu.ntiles, (uintptr_t)c->ilu.nsteps};
@@ -137,14 +137,22 @@ void pc_setup(tp_ctx *c) {
     Stencil Sl;
     Sl.base = c->Sm.p;
     Sl.slot_stride = c->g.ntot;
-    if (cptr && c->opt.schur_a11) {
+    const bool selfp = cptr && c->opt.schur_a11 == 2;
+    if (selfp) {
+        // pc_fieldsplit_schur_precondition selfp (pc_fieldsplit_selfp, singlephase.py:322-330)
+        TP_REQUIRE(c->opt.pc_kind == 2, "selfp is the single-phase pc_fieldsplit_selfp preset's Schur preconditioner");
+        TP_REQUIRE(!c->dist, "selfp needs the A00 diagonal and A01 rows of halo cells: one GPU only");
+        if (c->spbuf.n < (size_t)10 * c->g.ntot) c->spbuf.alloc((size_t)10 * c->g.ntot);
+        Sl.base = c->spbuf.p;                  // S7, filled by selfp_build on the stream of the S set-up below
+        Sl.slot_stride = c->g.ntot;
+    } else if (cptr && c->opt.schur_a11) {
         // pc_fieldsplit_schur_precondition a11 (singlephase.py:331-338, twophase.py:598-616): the T-T block of the
         // (decoupled) primary system stands in for the Schur complement
         Sl.base = c->opA00.base + 3 * (c->opA01.base - c->opA00.base);     // block (1,1) = 3 planes after (0,0)
         Sl.slot_stride = c->opA00.slot_stride;
         if (c->opt.decoup == 0) Sl.base = c->J.p + (long)(c->b + 1) * c->g.ntot;
     }
-    if (cptr) TP_REQUIRE(Sl.base, "pc_cptr needs the S~ operator (assemble with want_schur)");
+    if (cptr && !selfp) TP_REQUIRE(Sl.base, "pc_cptr needs the S~ operator (assemble with want_schur)");
     if (c->dist && c->amg_p->dist_levels == 0) {
         const size_t ng = (size_t)c->gfull.ntot;
         if (c->gA00.n < 7 * ng) {
@@ -181,6 +189,7 @@ void pc_setup(tp_ctx *c) {
         if (cptr) {
             TP_HIP(hipStreamWaitEvent(c->aux[1], c->ev_fork, 0));
             c->stream = c->aux[1];
+            if (selfp) selfp_build(c);
             amg_setup(c, c->amg_T, Sl);
             TP_HIP(hipEventRecord(c->ev_join[1], c->aux[1]));
         }
@@ -272,7 +281,13 @@ void stage1_apply(tp_ctx *c, const double *x, double *y, bool zero_secondary) {
     amg_vcycle(c, c->amg_p, r0, c->w4.p);                                   // y0 = K(A00) r0
     if (c->dist) halo_exchange(c, g, c->w4.p, 1, nt);
     spmv_scalar(c, g, c->opA10, c->w4.p, t, -1.0, r1);                      // t = r1 - A10 y0
-    amg_vcycle(c, c->amg_T, t, y1);                                         // y1 = K(S~) t
+    if (c->opt.schur_a11 == 2) {                                            // selfp: V7 then one Jacobi sweep on the exact Sp
+        double *xv = c->spbuf.p + 9 * nt;
+        amg_vcycle(c, c->amg_T, t, xv);
+        selfp_post(c, t, xv, y1);
+    } else {
+        amg_vcycle(c, c->amg_T, t, y1);                                     // y1 = K(S~) t
+    }
     if (c->dist) halo_exchange(c, g, y1, 1, nt);
     spmv_scalar(c, g, c->opA01, y1, t, -1.0, r0);                           // t = r0 - A01 y1
     amg_vcycle(c, c->amg_p, t, y0);                                         // y0 = K(A00) t

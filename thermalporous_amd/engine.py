@@ -74,6 +74,7 @@ DEFAULT_OPTS = dict(
     amg_dom_tau=0.25,       # relaxation-only truncation of diagonally dominant AMG hierarchies (oracle/linalg.py:SemiAMG)
     amg_gather_cells=2000000,
     schur_a11=False,
+    schur_selfp=False,      # pc_fieldsplit_schur_precondition selfp (pc_fieldsplit_selfp, singlephase.py:322-330)
     ilu_tile=None,          # None: whole axis-0 lines x 8 x 8 columns (3-D), x 32 columns (2-D); see default_ilu_tile
     ilu_levels=0,           # sub_1_sub_pc_factor_levels: 0 (block-ILU(0)) or 1 (block-ILU(1), pc_cprilu1_gmres)
     bjacobi_blocks=None,    # -sub_1_pc_bjacobi_blocks N: N blocks over the whole grid (tiles_for_blocks); overrides ilu_tile
@@ -250,7 +251,7 @@ class HipEngine:
                           o["ksp_restart"], o["snes_rtol"], o["snes_atol"], o["snes_stol"], o["snes_max_it"],
                           o["amg_omega"], o["amg_nu"], o["amg_min_cells"], int(min(t[1], 64)), int(min(t[2], 64)),
                           0 if t[0] >= (1 << 30) else int(t[0]), int(o["amg_full_levels"]), int(o["amg_coarse_pre"]),
-                          int(o["amg_coarse_post"]), int(bool(o["amg_mid_skip"])), int(o["amg_tail_post"]), int(bool(o["amg_single"])), int(bool(o["schur_a11"])),
+                          int(o["amg_coarse_post"]), int(bool(o["amg_mid_skip"])), int(o["amg_tail_post"]), int(bool(o["amg_single"])), 2 if o.get("schur_selfp") else int(bool(o["schur_a11"])),
                           int(o["amg_gather_cells"]), float(o.get("amg_dom_tau", 0.0)), int(o.get("ilu_levels", 0)))
 
     def set_options(self, **kw):

@@ -84,6 +84,7 @@ def engine_options(solver_parameters, model_name, decoup="No"):
     o = dict(DEFAULT_OPTS)
     o["decoup"] = decoup
     o["schur_a11"] = False
+    o["schur_selfp"] = False
     used = set()
     build_keys = ("amg_omega", "amg_nu", "amg_min_cells", "amg_full_levels", "amg_coarse_pre", "amg_coarse_post", "amg_mid_skip", "amg_tail_post", "amg_single",
                   "amg_gather_cells", "amg_dom_tau", "ilu_tile", "ilu_levels")
@@ -114,24 +115,26 @@ def engine_options(solver_parameters, model_name, decoup="No"):
                                   "are on the hot path")
     if pc_type == "fieldsplit":
         # pc_fieldsplit_cd (singlephase.py:309-319): Schur FULL on (p,T), V-cycle on A_pp, ConvDiffSchurPC on S;
-        # pc_fieldsplit_a11 (:331-338): A_TT stands in for the Schur complement
+        # pc_fieldsplit_a11 (:331-338): A_TT stands in for the Schur complement;
+        # pc_fieldsplit_selfp (:322-330): Sp = A_TT - A_Tp diag(A_pp)^-1 A_pT
         _take(sp, used, "pc_fieldsplit_type", ("schur",))
         fact = str(_take(sp, used, "pc_fieldsplit_schur_fact_type", None, "")).upper()
-        pre = _take(sp, used, "pc_fieldsplit_schur_precondition", ("a11",))
+        pre = _take(sp, used, "pc_fieldsplit_schur_precondition", ("a11", "selfp"))
         if "pc_fieldsplit_type" not in used or fact != "FULL":
-            raise NotImplementedError("fieldsplit preconditioners on the hot path: pc_fieldsplit_cd (schur FULL with "
-                                      "ConvDiffSchurPC) and pc_fieldsplit_a11; selfp / additive variants are not")
+            raise NotImplementedError("fieldsplit preconditioners on the hot path: schur FULL with ConvDiffSchurPC "
+                                      "(pc_fieldsplit_cd), a11 (pc_fieldsplit_a11) or selfp (pc_fieldsplit_selfp)")
         _take_vcycle(sp, "fieldsplit_0_", used)
-        if pre == "a11":
+        if pre in ("a11", "selfp"):
             _take_vcycle(sp, "fieldsplit_1_", used)
         else:
             _take(sp, used, "fieldsplit_1_ksp_type", ("preonly",))
             _take(sp, used, "fieldsplit_1_pc_type", ("python",))
             if not str(_take(sp, used, "fieldsplit_1_pc_python_type", None, "")).endswith("ConvDiffSchurPC"):
-                raise NotImplementedError("fieldsplit_1 must be ConvDiffSchurPC (pc_fieldsplit_cd) or a V-cycle on A_11 "
-                                          "(pc_fieldsplit_a11); selfp is not on the hot path")
+                raise NotImplementedError("fieldsplit_1 must be ConvDiffSchurPC (pc_fieldsplit_cd) or a V-cycle "
+                                          "(pc_fieldsplit_a11, pc_fieldsplit_selfp)")
             _take_vcycle(sp, "fieldsplit_1_schur_", used)
         o["schur_a11"] = pre == "a11"
+        o["schur_selfp"] = pre == "selfp"                # (singlephase.py:322-330)
         if model_name == "Two-phase":
             raise NotImplementedError("pc_fieldsplit_cd is the single-phase block preconditioner")
         if o["decoup"] != "No":
