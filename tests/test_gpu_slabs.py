@@ -87,7 +87,7 @@ def run_linear_stage(spec, opts, u0, u, dt, xs, nranks):
             h.vec_set("x", xs)
             h.pc_apply("x", "pc")
             res["pc"] = h.vec_get("pc")
-            out[rank] = (res, h.amg_layout(0))
+            out[rank] = (res, h.amg_layout(0), h.amg_trunc(1)[0] if opts["pc"] == "cptr" else None)
             h.close()
         except Exception as e:      # noqa: BLE001
             err.append((rank, repr(e)))
@@ -101,7 +101,8 @@ def run_linear_stage(spec, opts, u0, u, dt, xs, nranks):
         lib.tp_local_group_destroy(group)
     assert not err, err
     res = {k: np.concatenate([o[0][k] for o in out], axis=-3) for k in out[0][0]}
-    return res, out[0][1]
+    assert len({o[2] for o in out}) == 1        # every rank took the same relaxation-only truncation decision
+    return res, out[0][1], out[0][2]
 
 
 DIST_AMG_CASES = [
@@ -112,6 +113,9 @@ DIST_AMG_CASES = [
     ("2ph_cptr_v33", dict(Nx=5, Ny=24, Nz=6, nphase=2), dict(pc="cptr", amg_gather_cells=0, amg_nu=3, amg_full_levels=2)),
     ("2ph_cptr_partial", dict(Nx=8, Ny=21, Nz=7, nphase=2), dict(pc="cptr", amg_gather_cells=400)),
     ("1ph_cprQI", dict(Nx=6, Ny=17, Nz=5, nphase=1), dict(pc="cpr", decoup="QI", amg_gather_cells=0)),
+    # small dt: S~ is strongly diagonally dominant and its DISTRIBUTED level 0 ends the cycle (amg_dom_tau; the ranks
+    # agree on the decision through a max-all-reduce of the per-slab dominance ratios)
+    ("2ph_cptr_trunc", dict(Nx=8, Ny=21, Nz=7, nphase=2), dict(pc="cptr", amg_gather_cells=0, _dt=86.4)),
 ]
 
 
@@ -125,9 +129,13 @@ def test_distributed_amg_levels_equal_the_single_slab_hierarchy(name, kw, opts, 
     spec, u0, *_ = cases.c4_spe10_3d(**kw)
     u = cases.perturbed_state(spec, seed=5, amp=0.2)
     xs = np.random.default_rng(11).standard_normal(u.shape)
-    dt = 3000.0
-    one, lay1 = run_linear_stage(spec, opts, u0, u, dt, xs, 1)
-    many, layn = run_linear_stage(spec, opts, u0, u, dt, xs, nranks)
+    opts = dict(opts)
+    dt = opts.pop("_dt", 3000.0)
+    one, lay1, t1 = run_linear_stage(spec, opts, u0, u, dt, xs, 1)
+    many, layn, tn = run_linear_stage(spec, opts, u0, u, dt, xs, nranks)
+    assert t1 == tn                                                    # same cycle shape on one slab and on N
+    if name.endswith("trunc"):
+        assert 0 <= tn < layn[0], (tn, layn)                           # ... ending on a slab-distributed level
     assert lay1[0] == 0 and layn[0] >= 1 and lay1[1] == layn[1]        # same schedule, top levels distributed
     assert 2 in layn[1][:layn[0]] or name.endswith("partial")          # a distributed level coarsens the slab axis
     tol = 2e-6 if opts.get("amg_single") else 1e-11

@@ -833,9 +833,8 @@ static void setup_impl(tp_ctx *c, Amg *amg, const Stencil &A0) {
         L0->op.base = L0->A.p;
         L0->op.slot_stride = L0->g.ntot;
     }
-    // relaxation-only truncation: dominance ratios of the V(nu,nu) levels (replicated / single-slab hierarchies only: a
-    // slab-distributed level would need a max-all-reduce of its ratio)
-    const int nratio = (c->opt.amg_dom_tau > 0.0 && lg == 0) ? std::min({c->opt.amg_full_levels, (int)amg->lv.size() - 1, 8}) : 0;
+    // relaxation-only truncation: dominance ratios of the V(nu,nu) levels (slab-distributed levels: maximum over the ranks)
+    const int nratio = c->opt.amg_dom_tau > 0.0 ? std::min({c->opt.amg_full_levels, (int)amg->lv.size() - 1, 8}) : 0;
     if (nratio > 0) TP_HIP(hipMemsetAsync(amg->ratio_dev.p, 0, sizeof(double) * 64 * nratio, c->stream));
     for (size_t l = 0; l < amg->lv.size(); ++l) {
         AmgLevel *L = amg->lv[l];
@@ -874,6 +873,7 @@ static void setup_impl(tp_ctx *c, Amg *amg, const Stencil &A0) {
     amg->lvhost.assign((const char *)h.data(), (const char *)h.data() + h.size() * sizeof(LevelDevT<R>));
     TP_HIP(hipMemcpyAsync(amg->lvdev.p, amg->lvhost.data(), amg->lvhost.size(), hipMemcpyHostToDevice, c->stream));
     if (nratio > 0) {
+        if (lg > 0) allreduce_max(c, amg->ratio_dev.p, 64 * nratio);      // every rank takes the same decision
         TP_HIP(hipMemcpyAsync(amg->ratio_host, amg->ratio_dev.p, sizeof(double) * 64 * nratio, hipMemcpyDeviceToHost, c->stream));
         TP_HIP(hipEventRecord(amg->ev_ratio, c->stream));
         amg->ratio_pending = true;
@@ -978,6 +978,7 @@ static void vcycle_impl(tp_ctx *c, Amg *amg, const double *b, double *x) {
         AmgLevel *L = amg->lv[trunc];
         const double *bt = (trunc == 0) ? b : L->b.p;
         double *et = (trunc == 0) ? x : L->e.p;
+        hx(trunc, bt);                              // the fused double sweep reads invd*b of the neighbours
         hipLaunchKernelGGL(k_amg_pre<R>, xcd_grid(L->g.nown), bl, 0, c->stream, dev_of<R>(L, trunc, c->opt), bt, 1, et);
     } else {
         // the tail: every level from lt down to the coarsest (or the truncation level) and back, one launch

@@ -194,6 +194,27 @@ void allreduce_sum(tp_ctx *c, double *dev, int n) {
     TP_NCCL(ncclAllReduce(dev, dev, n, ncclDouble, ncclSum, (ncclComm_t)c->comm, c->stream));
 }
 
+// element-wise maximum over the ranks (non-negative doubles: the AMG dominance ratios)
+void allreduce_max(tp_ctx *c, double *dev, int n) {
+    if (!c->dist || n <= 0) return;
+    if (c->lgroup) {
+        LocalGroup *G = c->lgroup;
+        std::vector<double> &mine = G->red[c->grid.rank];
+        mine.resize(n);
+        TP_HIP(hipMemcpyAsync(mine.data(), dev, sizeof(double) * n, hipMemcpyDeviceToHost, c->stream));
+        TP_HIP(hipStreamSynchronize(c->stream));
+        G->barrier();
+        std::vector<double> mx(n, 0.0);
+        for (int r = 0; r < G->n; ++r)
+            for (int i = 0; i < n; ++i) mx[i] = std::max(mx[i], G->red[r][i]);
+        G->barrier();                                  // everybody has read before anybody overwrites
+        TP_HIP(hipMemcpyAsync(dev, mx.data(), sizeof(double) * n, hipMemcpyHostToDevice, c->stream));
+        TP_HIP(hipStreamSynchronize(c->stream));
+        return;
+    }
+    TP_NCCL(ncclAllReduce(dev, dev, n, ncclDouble, ncclMax, (ncclComm_t)c->comm, c->stream));
+}
+
 }  // namespace tp
 
 tp_ctx::~tp_ctx() {

@@ -293,6 +293,7 @@ void halo_exchange_raw(tp_ctx *c, const GridDev &g, void *x, int nf, size_t fstr
 void gather_ranges(tp_ctx *c, void *global, long np, const std::vector<std::pair<int, int>> &ranges, int nslots,
                    size_t slot_stride_bytes, size_t elem_bytes);
 void allreduce_sum(tp_ctx *c, double *dev, int n);
+void allreduce_max(tp_ctx *c, double *dev, int n);
 void slab_of(const tp_ctx *c, int rank, int &lo, int &hi);
 // gather `nplanes` slab-distributed cell planes into arrays on the global grid (every rank gets all slabs)
 void gather_slabs(tp_ctx *c, const double *local, long lstride, double *global, long gstride, int nplanes);
