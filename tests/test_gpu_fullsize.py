@@ -138,6 +138,73 @@ def test_c4_true_size_vs_cport():
     h.close()
 
 
+def test_c2_true_size_selfp_60x220():
+    """pc_fieldsplit_selfp (singlephase.py:322-330) at BASELINE config 2's size: the Sp collapse / exact-Sp sweep stage,
+    the whole Schur-FULL preconditioner and FGMRES, HIP vs the numpy oracle."""
+    import oracle.linalg as la
+    from oracle.engine import OracleEngine
+    from thermalporous_amd.engine import HipEngine
+    spec, u0, *_ = cases.c3_spe10_2d(Nx=60, Ny=220, nphase=1)
+    opts = dict(pc="fieldsplit_cd", schur_selfp=True, ksp_rtol=1e-8)
+    o, h = OracleEngine(spec, opts), HipEngine(spec, opts)
+    u = cases.perturbed_state(spec, seed=3, amp=0.3)
+    for e in (o, h):
+        e.set_old(u0)
+        e.set_dt(8640.0)
+        e.set_state(u)
+    J, Sm = _check_assembly(o, h, True)
+    o.pc.setup(J, Sm)
+    h.pc_setup()
+    x = np.random.default_rng(11).standard_normal(J.shape[1:2] + J.shape[3:])
+    h.vec_set("x", x)
+    h.amg_vcycle(1, "x", 1, "y", 1)                  # V7: the hierarchy of Sp's 7-point collapse
+    assert rel2(h.vec_get("y")[1], o.pc.selfp.amg.vcycle(x[1])) < 1e-9
+    h.pc_apply("x", "y")
+    assert rel2(h.vec_get("y"), o.pc.apply(x)) < 1e-9
+    F = o.residual()
+    h.residual()
+    h.copy_residual_to("b")
+    its_h, reason_h, _ = h.fgmres("b", "d")
+    d_o, its_o, reason_o, _ = la.fgmres(lambda v: la.spmv_block(J, v), o.pc.apply, F, rtol=1e-8)
+    assert reason_h == reason_o == 2 and abs(its_h - its_o) <= 1, (its_h, its_o)
+    assert rel2(h.vec_get("d"), d_o) < 1e-6
+    h.close()
+
+
+def test_c4_true_size_ilu1_vs_cport():
+    """Block-ILU(1) second stage (pc_cprilu1_gmres, twophase.py:653-668) at BASELINE config 4's size, default tiles
+    (250 tiles of 85 x 6 x 9 cells, 127 wavefront steps): sweeps, whole preconditioner, FGMRES -- HIP vs oracle/cport."""
+    from oracle.cport import CPortEngine
+    from thermalporous_amd.engine import HipEngine
+    spec, u0, *_ = cases.c4_spe10_3d(60, 220, 85)
+    opts = dict(pc="cpr", ilu_levels=1, ksp_rtol=1e-8, snes_max_it=25)
+    c, h = CPortEngine(spec, opts), HipEngine(spec, opts)
+    u = cases.perturbed_state(spec, seed=1, amp=0.05)
+    for e in (c, h):
+        e.set_old(u0)
+        e.set_dt(600.0)
+        e.set_state(u)
+    c.residual()
+    c.jacobian()
+    h.jacobian()
+    c.pc_setup()
+    h.pc_setup()
+    x = np.random.default_rng(11).standard_normal(u.shape)
+    h.vec_set("x", x)
+    h.ilu_solve("x", "y")
+    assert rel2(h.vec_get("y"), c.ilu_solve(x)) < 1e-10
+    h.pc_apply("x", "y")
+    assert rel2(h.vec_get("y"), c.pc_apply(x)) < 1e-9
+    F = c.residual()
+    h.residual()
+    h.copy_residual_to("b")
+    its_h, reason_h, _ = h.fgmres("b", "d")
+    d_c, its_c, reason_c, _ = c.fgmres(F)
+    assert reason_h == reason_c == 2 and abs(its_h - its_c) <= 1, (its_h, its_c)
+    assert rel2(h.vec_get("d"), d_c) < 1e-6
+    h.close()
+
+
 def _c5_slab_spec():
     """One of the 8 slabs of BASELINE config 5: 240x110x340 cells of 1/4 SPE10 size, 21+21 'large' wells + heaters."""
     import bench
