@@ -68,7 +68,8 @@ typedef struct tp_options {
                                 (single-phase: fieldsplit Schur FULL on (p,T) with V(App) and the
                                 ConvDiffSchurPC V(S~), no second stage; singlephase.py:309-319),
                                 3 = pc_cptramg[_QI|_TI] (CPTRStage1PC with ONE system-AMG V-cycle on the 2x2-block
-                                (p,T) operator Atilde_00 + bjacobi/ILU0; twophase.py:552-566) */
+                                (p,T) operator Atilde_00 + bjacobi/ILU0; twophase.py:552-566),
+                                4 = pc_bilu (bjacobi + ILU(ilu_levels) alone; twophase.py:758-762, singlephase.py:402-406) */
     int32_t decoup;          /* 0 "No", 1 "QI", 2 "TI", 3 "QI_temp", 4 "TI_temp" (option key sub_0_cpr_decoup;
                                 the _temp variants decouple both T and S: two-phase pc_cpr only) */
     double  ksp_rtol, ksp_atol;

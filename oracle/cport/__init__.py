@@ -18,7 +18,7 @@ _LIB = None
 
 _PRM = ("ko", "kw", "kr", "c_v_w", "c_v_o", "c_r", "rho_r", "p_inj", "p_prod", "T_inj", "T_prod", "API", "p_ref", "g",
         "S_o", "U", "rate")
-_PC = {"cpr": 0, "cptr": 1, "fieldsplit_cd": 2}
+_PC = {"cpr": 0, "cptr": 1, "fieldsplit_cd": 2, "bilu": 4}
 _DECOUP = {"No": 0, "QI": 1, "TI": 2, "QI_temp": 3, "TI_temp": 4}
 
 

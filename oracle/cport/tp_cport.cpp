@@ -86,7 +86,7 @@ struct Prm {
 };
 
 struct Opts {
-    int32_t pc;           // 0 cpr, 1 cptr, 2 fieldsplit_cd
+    int32_t pc;           // 0 cpr, 1 cptr, 2 fieldsplit_cd, 4 bilu (bjacobi + ILU alone)
     int32_t decoup;       // 0 No, 1 QI, 2 TI, 3 QI_temp, 4 TI_temp
     double ksp_rtol, ksp_atol;
     int32_t ksp_max_it, ksp_restart;
@@ -1226,6 +1226,7 @@ static void pc_setup(Ctx &C) {
     const int b = C.b;
     if (C.tiles.empty()) ilu_layout(C);
     ilu_factor_any(C);
+    if (C.o.pc == 4) return;                  // pc_bilu: bjacobi + ILU alone
     const int npri = C.o.pc == 0 ? 1 : 2;
     C.have_d = C.o.decoup != 0;
     if (C.have_d) {
@@ -1340,6 +1341,11 @@ static void stage1(Ctx &C, const double *x, double *y) {      // TwoStagePC.stag
 static void pc_apply(Ctx &C, const double *x, double *y) {      // TwoStagePC.apply
     const long N = C.g.N;
     const int b = C.b;
+    if (C.o.pc == 4) {
+        if (C.w_yt.size() != (size_t)b * N) C.w_yt.assign((size_t)b * N, 0.0);
+        ilu_solve_any(C, x, y, C.w_yt.data());
+        return;
+    }
     stage1(C, x, y);
     if (C.o.pc == 2) return;
     double *r = C.w_res.data(), *z = C.w_il.data();

@@ -727,6 +727,8 @@ class TwoStagePC:
         o = self.o
         self.J = J
         self.ilu.factor(J)
+        if o["pc"] == "bilu":
+            return                                   # pc_bilu (twophase.py:758-762, singlephase.py:402-406): stage 2 alone
         if o["pc"] == "cpr":
             At, self.d = decouple(J, o["decoup"], [0])
             self.amg_p.setup(At[:, 0, 0])
@@ -790,6 +792,8 @@ class TwoStagePC:
         return y
 
     def apply(self, x):
+        if self.o["pc"] == "bilu":
+            return self.ilu.solve(x)
         y = self.stage1(x)
         if self.o["pc"] == "fieldsplit_cd":
             return y

@@ -131,3 +131,28 @@ def test_cport_time_loop_and_budget():
     c.set_dt(86.4)
     r = c.newton_solve(budget_s=1e-9)         # at least one Newton iteration always completes
     assert r["nits"] == 1 and r["complete"] == 0 and r["reason"] == 0 and r["lits"] > 0
+
+
+@pytest.mark.parametrize("levels", [0, 1])
+def test_cport_bilu_matches_numpy_oracle(levels):
+    """pc_bilu (twophase.py:758-762): bjacobi + block-ILU(levels) alone as the preconditioner."""
+    spec, u0, *_ = cases.c4_spe10_3d(Nx=9, Ny=14, Nz=8, nphase=2)
+    opts = dict(pc="bilu", ilu_levels=levels, ilu_tile=(5, 4, 7))
+    o, c = OracleEngine(spec, opts), CPortEngine(spec, opts)
+    u = cases.perturbed_state(spec, seed=5, amp=0.3)
+    for e in (o, c):
+        e.set_old(u0)
+        e.set_dt(864.0)
+        e.set_state(u)
+    J = o.jacobian()
+    c.jacobian()
+    o.pc.setup(J)
+    c.pc_setup()
+    x = np.random.default_rng(11).standard_normal(u.shape)
+    assert rel2(c.pc_apply(x), o.pc.ilu.solve(x)) < 1e-13
+    F = o.residual()
+    d_o, its_o, reason_o, _ = la.fgmres(lambda v: la.spmv_block(J, v), o.pc.apply, F, rtol=o.opts["ksp_rtol"],
+                                        maxit=o.opts["ksp_max_it"], restart=o.opts["ksp_restart"])
+    d_c, its_c, reason_c, _ = c.fgmres(F)
+    assert reason_c == reason_o == 2 and its_c == its_o
+    assert rel2(d_c, d_o) < 1e-7

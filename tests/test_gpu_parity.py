@@ -211,6 +211,36 @@ def test_newton_parity(name, builder, kw, opts, dt):
     h.close()
 
 
+@pytest.mark.parametrize("levels,nphase", [(0, 2), (1, 2), (1, 1)])
+def test_bilu_preset_stage(levels, nphase):
+    """pc_bilu (twophase.py:758-762, singlephase.py:402-406): bjacobi + block-ILU(levels) alone -- pc_apply IS the sweep,
+    FGMRES iteration counts equal the oracle's."""
+    import oracle.linalg as la
+    spec, u0, o, h = make(cases.c4_spe10_3d, dict(pc="bilu", ilu_levels=levels, ilu_tile=(5, 4, 7)), Nx=9, Ny=14, Nz=8, nphase=nphase)
+    u = cases.perturbed_state(spec, seed=5, amp=0.3)
+    for e in (o, h):
+        e.set_old(u0)
+        e.set_dt(864.0)
+        e.set_state(u)
+    J = o.jacobian()
+    h.jacobian()
+    o.pc.setup(J)
+    h.pc_setup()
+    x = np.random.default_rng(11).standard_normal(u.shape)
+    h.vec_set("x", x)
+    h.pc_apply("x", "y")
+    assert rel2(h.vec_get("y"), o.pc.ilu.solve(x)) < 1e-10
+    F = o.residual()
+    h.residual()
+    h.copy_residual_to("b")
+    its_h, reason_h, _ = h.fgmres("b", "d")
+    d_o, its_o, reason_o, _ = la.fgmres(lambda v: la.spmv_block(J, v), o.pc.apply, F, rtol=o.opts["ksp_rtol"],
+                                        maxit=o.opts["ksp_max_it"], restart=o.opts["ksp_restart"])
+    assert reason_h == reason_o == 2 and abs(its_h - its_o) <= 1, (its_h, its_o)
+    assert rel2(h.vec_get("d"), d_o) < 1e-6
+    h.close()
+
+
 def test_exported_vector_ops():
     """tp_vec_dot_batch / tp_vec_axpy_batch / tp_vec_norm2 (VecMDot, VecMAXPY, VecNorm of one Krylov iteration) vs numpy."""
     from thermalporous_amd.engine import HipEngine

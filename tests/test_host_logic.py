@@ -175,6 +175,13 @@ def test_solver_option_mapping_and_rejections():
     assert m7.engine_opts["pc"] == "cpr" and m7.engine_opts["ilu_levels"] == 1
     with pytest.raises(NotImplementedError):
         engine_options({**m5.solver_parameters, "sub_1_sub_pc_factor_levels": 2}, "Two-phase")
+    # pc_bilu (twophase.py:758-762, singlephase.py:402-406): bjacobi + ILU(1) alone
+    m8b = TwoPhase(g, c2, p2, solver_parameters="pc_bilu", filename=None, verbosity=False, _engine_factory=OracleEngine)
+    assert m8b.engine_opts["pc"] == "bilu" and m8b.engine_opts["ilu_levels"] == 1
+    m8c = SinglePhase(g, c, p, solver_parameters="pc_bilu", filename=None, verbosity=False, _engine_factory=OracleEngine)
+    assert m8c.engine_opts["pc"] == "bilu" and m8c.engine_opts["ilu_levels"] == 1
+    with pytest.raises(NotImplementedError):
+        engine_options({**m8c.solver_parameters, "sub_pc_type": "lu"}, "Single phase")
     with pytest.raises(NotImplementedError):
         engine_options({"pc_type": "lu", "ksp_type": "preonly"}, "Single phase")
     with pytest.raises(KeyError):

@@ -105,6 +105,12 @@ static void pc_setup_sysamg(tp_ctx *c) {
 void pc_setup(tp_ctx *c) {
     TP_REQUIRE(c->jac_ready, "pc_setup needs an assembled Jacobian");
     ensure_work(c);
+    if (c->opt.pc_kind == 4) {               // pc_bilu (twophase.py:758-762): bjacobi + ILU is the whole preconditioner
+        ilu_factor(c);
+        c->pc_ready = true;
+        refresh_pc_signature(c);
+        return;
+    }
     if (sysamg_of(c->opt)) { pc_setup_sysamg(c); return; }
     const bool cptr = schur_of(c->opt);       // fieldsplit-Schur stage on (p,T): pc_cptr and pc_fieldsplit_cd
     if (c->opt.pc_kind == 1) TP_REQUIRE(c->b == 3, "pc_cptr is a two-phase preconditioner");
@@ -295,6 +301,7 @@ void stage1_apply(tp_ctx *c, const double *x, double *y, bool zero_secondary) {
 
 // composite multiplicative: y = B1 x ; r = x - J y ; y += B2 r
 static void pc_apply_body(tp_ctx *c, const double *x, double *y) {
+    if (c->opt.pc_kind == 4) { ilu_solve(c, x, y, nullptr, 0); return; }
     const int npri = npri_of(c->opt);
     // (y's secondary fields are left untouched: the second stage below never reads them and overwrites them)
     stage1_apply(c, x, y, false);                 // multi-GPU, replicated stage 1: y comes back with live halo planes
@@ -311,7 +318,7 @@ static void pc_apply_body(tp_ctx *c, const double *x, double *y) {
 void pc_apply(tp_ctx *c, const double *x, double *y) {
     TP_REQUIRE(c->pc_ready, "pc_apply before pc_setup");
     static const bool use_graph = !(getenv("TP_GRAPH") && atoi(getenv("TP_GRAPH")) == 0);
-    c->vcycles += schur_of(c->opt) ? 3 : 1;
+    c->vcycles += c->opt.pc_kind == 4 ? 0 : schur_of(c->opt) ? 3 : 1;
     ensure_work(c);                      // never allocate inside a stream capture
     resolve_cycle_shapes(c);             // (waits for the last set-up's dominance ratios: not inside a capture either)
     if (!use_graph || c->dist) {

@@ -146,7 +146,7 @@ def tiles_for_blocks(n, nblocks, max_cols=64):
     return best[1]
 
 
-_PC = {"cpr": 0, "cptr": 1, "fieldsplit_cd": 2, "cptramg": 3}
+_PC = {"cpr": 0, "cptr": 1, "fieldsplit_cd": 2, "cptramg": 3, "bilu": 4}
 _DECOUP = {"No": 0, "QI": 1, "TI": 2, "QI_temp": 3, "TI_temp": 4}
 
 

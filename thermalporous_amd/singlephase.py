@@ -86,6 +86,7 @@ class SinglePhase(ThermalModel):
         presets = {"pc_fieldsplit_a11": pc_fieldsplit_a11, "pc_fieldsplit_selfp": pc_fieldsplit_selfp, "pc_cpr": pc_cpr,
                    "pc_cpr_QI": {**pc_cpr, "sub_0_cpr_decoup": "QI"},      # (:353)
                    "pc_cpr_TI": {**pc_cpr, "sub_0_cpr_decoup": "TI"},      # (:354)
+                   "pc_bilu": {"pc_type": "bjacobi", "sub_pc_type": "ilu", "sub_pc_factor_levels": 1, "mat_type": "aij"},   # (402-406)
                    "pc_fieldsplit_cd": pc_fieldsplit_cd,
                    "pc_cpr_gmres": {"pc_type": "composite",        # (:355-368) pure-PETSc emulation of pc_cpr
                                     "pc_composite_type": "multiplicative",

@@ -109,7 +109,25 @@ def engine_options(solver_parameters, model_name, decoup="No"):
         if k_src in sp:
             o[k_dst] = sp[k_src]
             used.add(k_src)
-    pc_type = _take(sp, used, "pc_type", ("fieldsplit", "composite"))
+    pc_type = _take(sp, used, "pc_type", ("fieldsplit", "composite", "bjacobi"))
+    if pc_type == "bjacobi":
+        # pc_bilu (twophase.py:758-762, singlephase.py:402-406): bjacobi + ILU(levels) is the whole preconditioner
+        _take(sp, used, "sub_pc_type", ("ilu",))
+        if "sub_pc_type" not in used:
+            raise NotImplementedError("pc_type bjacobi: sub_pc_type ilu only (pc_bilu)")
+        levels = int(_take(sp, used, "sub_pc_factor_levels", None, 0))
+        if levels not in (0, 1):
+            raise NotImplementedError("bjacobi sub-solver is block-ILU(0) or block-ILU(1) (sub_pc_factor_levels %d)" % levels)
+        o["ilu_levels"] = levels
+        nb = _take(sp, used, "pc_bjacobi_blocks")
+        if nb is not None:
+            o["bjacobi_blocks"] = int(nb)
+        _take(sp, used, "mat_type", ("aij",))
+        if o["decoup"] != "No":
+            raise NotImplementedError("pc_bilu has no decoupling stage")
+        o["pc"] = "bilu"
+        _reject_unused(sp, used)
+        return o
     if pc_type is None:
         raise NotImplementedError("pc_type missing: only the composite CPR/CPTR preconditioners and pc_fieldsplit_cd/_a11 "
                                   "are on the hot path")
