@@ -105,6 +105,8 @@ typedef struct tp_options {
     int32_t ilu_levels;      /* stage 2 fill level: 0 = block-ILU(0) (sub_1_sub_pc_factor_levels 0, the presets' default),
                                 1 = block-ILU(1) (pc_cprilu1_gmres, twophase.py:653-668): 13-block rows, the sweeps
                                 take 4 steps of skew per axis-2 plane and 2 per axis-1 line instead of 1 and 1 */
+    int32_t fs_additive;     /* pc_kind 2: 1 = PCFIELDSPLIT additive on (p,T) -- y_p = V(A_pp) x_p, y_T = V(A_TT) x_T, no coupling
+                                (pc_fieldsplit_diag, singlephase.py:371-375) -- instead of Schur FULL */
 } tp_options;
 
 /* Result of one nonlinear solve (SNES iteration number / linear iterations / reason:

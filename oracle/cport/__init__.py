@@ -30,7 +30,7 @@ class _Opts(C.Structure):
                 ("amg_full_levels", C.c_int32), ("amg_coarse_pre", C.c_int32), ("amg_coarse_post", C.c_int32),
                 ("amg_mid_skip", C.c_int32), ("amg_tail_post", C.c_int32), ("amg_single", C.c_int32),
                 ("schur_a11", C.c_int32), ("tile", C.c_int32*3), ("nslabs", C.c_int32), ("amg_dom_tau", C.c_double),
-                ("ilu_levels", C.c_int32)]
+                ("ilu_levels", C.c_int32), ("fs_additive", C.c_int32)]
 
 
 class _Info(C.Structure):
@@ -118,7 +118,7 @@ class CPortEngine:
                         o["amg_min_cells"], int(o.get("amg_full_levels", 99)), neg(o.get("amg_coarse_pre")),
                         neg(o.get("amg_coarse_post")), int(bool(o.get("amg_mid_skip", False))), neg(o.get("amg_tail_post")),
                         int(bool(o.get("amg_single", False))), 2 if o.get("schur_selfp") else int(bool(o.get("schur_a11", False))), (C.c_int32*3)(*t),
-                        int(o.get("nslabs", 1)), float(o.get("amg_dom_tau", 0.0)), int(o.get("ilu_levels", 0)))
+                        int(o.get("nslabs", 1)), float(o.get("amg_dom_tau", 0.0)), int(o.get("ilu_levels", 0)), int(bool(o.get("fs_additive", False))))
         prm = np.array([float(spec["prm"][k]) for k in _PRM])
         kT = spec.get("kT")
         self.ctx = C.c_void_p(self.lib.cp_create(

@@ -99,6 +99,7 @@ struct Opts {
     int32_t nslabs;
     double amg_dom_tau;
     int32_t ilu_levels;   // 0 or 1 (sub_1_sub_pc_factor_levels)
+    int32_t fs_additive;  // pc_kind 2: additive (block-diagonal) fieldsplit instead of Schur FULL (pc_fieldsplit_diag)
 };
 
 struct Info {
@@ -1278,7 +1279,7 @@ static void pc_setup(Ctx &C) {
     if (C.o.pc >= 1) {
         SView S;
         if (C.o.schur_a11 == 2) { selfp_build(C); S.base = C.sp_S7.data(); S.cs = 7; S.ss = 1; }
-        else if (C.o.schur_a11) S = blk(C, 1, 1);
+        else if (C.o.schur_a11 || C.o.fs_additive) S = blk(C, 1, 1);
         else { S.base = C.Sm.data(); S.cs = 7; S.ss = 1; }
         C.amg_T.setup(S);
     }
@@ -1317,6 +1318,11 @@ static void stage1(Ctx &C, const double *x, double *y) {      // TwoStagePC.stag
     }
     const SView A10 = blk(C, 1, 0), A01 = blk(C, 0, 1);
     double *y0 = C.w_y0.data(), *t = C.w_t.data();
+    if (C.o.fs_additive) {                 // PCFIELDSPLIT additive: one V-cycle per field, no coupling
+        C.amg_p.vcycle(r0, y);
+        C.amg_T.vcycle(r1, y + N);
+        return;
+    }
     C.amg_p.vcycle(r0, y0);
     spmv_scalar(C.g, A10, y0, t);
 #pragma omp parallel for schedule(static)

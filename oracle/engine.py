@@ -25,6 +25,7 @@ DEFAULT_OPTS = dict(
     snes_rtol=1e-8, snes_atol=1e-50, snes_stol=1e-8, snes_max_it=15,
     amg_omega=0.8, amg_min_cells=64, amg_nu=2, amg_full_levels=3, amg_coarse_pre=0, amg_coarse_post=1, amg_mid_skip=True, amg_tail_post=2, amg_single=False,
     schur_a11=False,
+    fs_additive=False,      # pc_fieldsplit_type additive on (p,T): pc_fieldsplit_diag (singlephase.py:371-375)
     schur_selfp=False,      # pc_fieldsplit_schur_precondition selfp (pc_fieldsplit_selfp, singlephase.py:322-330)
     amg_dom_tau=0.25,       # relaxation-only truncation of diagonally dominant AMG hierarchies (oracle/linalg.py:SemiAMG)
     amg_gather_cells=2000000,     # GPU multi-slab execution detail (same algebra): ignored here

@@ -756,7 +756,7 @@ class TwoStagePC:
                 self.selfp = SelfpSchur(self.amg_T, o["amg_omega"]).setup(At[:, 0, 0], At[:, 0, 1], At[:, 1, 0], At[:, 1, 1])
             else:
                 self.selfp = None
-                self.amg_T.setup(self.At[:, 1, 1] if o.get("schur_a11") else Sm)     # (singlephase.py:331-338: a11)
+                self.amg_T.setup(self.At[:, 1, 1] if (o.get("schur_a11") or o.get("fs_additive")) else Sm)     # (singlephase.py:331-338: a11)
         else:
             raise ValueError(o["pc"])
 
@@ -782,6 +782,11 @@ class TwoStagePC:
             r0 = x[0] if self.d is None else x[0] - self.d[0] * x[s]
             r1 = x[1] if self.d is None else x[1] - self.d[1] * x[s]
             At = self.At
+            if o.get("fs_additive"):
+                # PCFIELDSPLIT additive (pc_fieldsplit_diag, singlephase.py:371-375): block-diagonal, one V-cycle per field
+                y[0], y[1] = self.amg_p.vcycle(r0), self.amg_T.vcycle(r1)
+                self.vcycles += 2
+                return y
             # PCFIELDSPLIT schur FULL: y0 = K(A00) r0; y1 = K(S)(r1 - A10 y0); y0 = K(A00)(r0 - A01 y1)
             y0 = self.amg_p.vcycle(r0)
             KS = self.selfp.vcycle if getattr(self, "selfp", None) is not None else self.amg_T.vcycle

@@ -32,6 +32,8 @@ CASES = [
     # Schur complement preconditioned by selfp (pc_fieldsplit_selfp, singlephase.py:322-330)
     ("c4_1ph_3d_selfp", cases.c4_spe10_3d, dict(Nx=7, Ny=13, Nz=9, nphase=1), dict(pc="fieldsplit_cd", schur_selfp=True)),
     ("c2_1ph_2d_selfp", cases.c3_spe10_2d, dict(Nx=14, Ny=19, nphase=1), dict(pc="fieldsplit_cd", schur_selfp=True)),
+    # additive fieldsplit on (p,T): pc_fieldsplit_diag (singlephase.py:371-375)
+    ("c4_1ph_3d_fsdiag", cases.c4_spe10_3d, dict(Nx=7, Ny=13, Nz=9, nphase=1), dict(pc="fieldsplit_cd", schur_a11=True, fs_additive=True)),
     # block-ILU(1) second stage (pc_cprilu1_gmres, twophase.py:653-668)
     ("c4_2ph_3d_ilu1", cases.c4_spe10_3d, dict(Nx=11, Ny=13, Nz=17, nphase=2), dict(pc="cpr", ilu_levels=1, ilu_tile=(5, 4, 7))),
     ("c4_2ph_3d_cptr_ilu1", cases.c4_spe10_3d, dict(Nx=9, Ny=14, Nz=8, nphase=2), dict(pc="cptr", ilu_levels=1)),

@@ -114,18 +114,23 @@ def test_fieldsplit_cd_preset_and_pc_classes():
     h.close()
 
 
-@pytest.mark.parametrize("preset", ["pc_fieldsplit_selfp", "pc_fieldsplit_a11"])
+@pytest.mark.parametrize("preset", ["pc_fieldsplit_selfp", "pc_fieldsplit_a11", "pc_fieldsplit_diag", "pc_bilu"])
 def test_single_phase_schur_presets_time_loop(preset):
-    """pc_fieldsplit_selfp (singlephase.py:322-330) and pc_fieldsplit_a11 (:331-338) through SinglePhase.solve() on the
+    """pc_fieldsplit_selfp (singlephase.py:322-330), pc_fieldsplit_a11 (:331-338), pc_fieldsplit_diag (:371-375) and pc_bilu
+    (:402-406) through SinglePhase.solve() on the
     SPE10-like 2-D case: HIP engine vs oracle engine, same Newton counts, Krylov counts +-1, same converged state."""
     from oracle.engine import OracleEngine
     from thermalporous_amd.singlephase import SinglePhase
     res = []
     for factory in (OracleEngine, None):
         spec, u0, p, g, c = cases.c3_spe10_2d(Nx=14, Ny=19, nphase=1)
-        m = SinglePhase(g, c, p, end=0.5, maxdt=0.25, small_dt_start=False, solver_parameters=preset, filename=None,
+        # (the block-diagonal preset is a weak preconditioner: at dt = 0.25 d its fourth Newton iterate asks FGMRES for a
+        # residual below what float64 can deliver on this matrix -- in the oracle as on the GPU -- so it runs at dt = 0.01 d)
+        end, maxdt = (0.02, 0.01) if preset == "pc_fieldsplit_diag" else (0.5, 0.25)
+        m = SinglePhase(g, c, p, end=end, maxdt=maxdt, small_dt_start=False, solver_parameters=preset, filename=None,
                         verbosity=False, _engine_factory=factory)
         assert m.engine_opts["schur_selfp"] == (preset == "pc_fieldsplit_selfp")
+        assert m.engine_opts["fs_additive"] == (preset == "pc_fieldsplit_diag")
         m.solve()
         res.append((m.nits_vec, m.lits_vec, m.u.dat.data_ro[0].copy(), m.u.dat.data_ro[1].copy()))
     assert res[0][0] == res[1][0] and len(res[0][0]) >= 2

@@ -175,6 +175,13 @@ def test_solver_option_mapping_and_rejections():
     assert m7.engine_opts["pc"] == "cpr" and m7.engine_opts["ilu_levels"] == 1
     with pytest.raises(NotImplementedError):
         engine_options({**m5.solver_parameters, "sub_1_sub_pc_factor_levels": 2}, "Two-phase")
+    # pc_fieldsplit_diag (singlephase.py:371-375): additive fieldsplit = V(A_pp) + V(A_TT)
+    m8d = SinglePhase(g, c, p, solver_parameters="pc_fieldsplit_diag", filename=None, verbosity=False, _engine_factory=OracleEngine)
+    assert m8d.engine_opts["pc"] == "fieldsplit_cd" and m8d.engine_opts["fs_additive"] is True and m3.engine_opts["fs_additive"] is False
+    # pc_cptramg_gmres (twophase.py:698-713): the pure-PETSc emulation of pc_cptramg; forces vector=True (:953-955)
+    m8e = TwoPhase(g, c2, p2, solver_parameters="pc_cptramg_gmres", filename=None, verbosity=False, _engine_factory=OracleEngine)
+    assert m8e.engine_opts["pc"] == "cptramg" and m8e.vector is True and m8e.engine_opts["decoup"] == "No"
+    assert m5.engine_opts["pc"] == "cpr"            # (pc_cpr_gmres names its fields: pressure only)
     # pc_bilu (twophase.py:758-762, singlephase.py:402-406): bjacobi + ILU(1) alone
     m8b = TwoPhase(g, c2, p2, solver_parameters="pc_bilu", filename=None, verbosity=False, _engine_factory=OracleEngine)
     assert m8b.engine_opts["pc"] == "bilu" and m8b.engine_opts["ilu_levels"] == 1

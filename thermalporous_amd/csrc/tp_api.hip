@@ -336,7 +336,7 @@ int tp_set_options(tp_ctx *c, const tp_options *opt) {
                              opt->amg_tail_post != c->opt.amg_tail_post || opt->amg_mid_skip != c->opt.amg_mid_skip ||
                              opt->amg_dom_tau != c->opt.amg_dom_tau ||
                              opt->amg_single != c->opt.amg_single || opt->amg_gather_cells != c->opt.amg_gather_cells ||
-                             opt->schur_a11 != c->opt.schur_a11;
+                             opt->schur_a11 != c->opt.schur_a11 || opt->fs_additive != c->opt.fs_additive;
     c->opt = *opt;
     if (tile_changed) c->ilu.slots = 0;
     if (amg_changed) {

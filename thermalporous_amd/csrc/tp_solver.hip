@@ -65,7 +65,7 @@ static void refresh_pc_signature(tp_ctx *c) {
                              (uintptr_t)c->Sm.p, (uintptr_t)c->ilu.fwd.p, (uintptr_t)c->amg_p, (uintptr_t)c->amg_T, (uintptr_t)c->bamg,
                              (uintptr_t)c->w1.p, (uintptr_t)c->w3.p, (uintptr_t)c->w4.p, (uintptr_t)c->dcoef.p, (uintptr_t)c->spbuf.p,
                              (uintptr_t)c->opt.amg_nu, (uintptr_t)c->opt.pc_kind, (uintptr_t)c->opt.decoup,
-                             (uintptr_t)c->opt.amg_single, (uintptr_t)c->opt.amg_gather_cells, (uintptr_t)c->opt.schur_a11, (uintptr_t)c->opt.amg_full_levels, (uintptr_t)c->opt.amg_coarse_pre, (uintptr_t)c->opt.amg_coarse_post, (uintptr_t)c->opt.amg_tail_post, (uintptr_t)c->opt.amg_mid_skip,
+                             (uintptr_t)c->opt.amg_single, (uintptr_t)c->opt.amg_gather_cells, (uintptr_t)c->opt.schur_a11, (uintptr_t)c->opt.fs_additive, (uintptr_t)c->opt.amg_full_levels, (uintptr_t)c->opt.amg_coarse_pre, (uintptr_t)c->opt.amg_coarse_post, (uintptr_t)c->opt.amg_tail_post, (uintptr_t)c->opt.amg_mid_skip,
                              (uintptr_t)c->ilu.ntiles, (uintptr_t)c->ilu.nsteps};
     uintptr_t h = 1469598103934665603ull;
     for (uintptr_t v : sig) h = (h ^ v) * 1099511628211ull;
@@ -143,6 +143,7 @@ void pc_setup(tp_ctx *c) {
     Stencil Sl;
     Sl.base = c->Sm.p;
     Sl.slot_stride = c->g.ntot;
+    if (c->opt.fs_additive) TP_REQUIRE(c->opt.pc_kind == 2 && c->opt.schur_a11 != 2, "fs_additive is the single-phase pc_fieldsplit_diag preset");
     const bool selfp = cptr && c->opt.schur_a11 == 2;
     if (selfp) {
         // pc_fieldsplit_schur_precondition selfp (pc_fieldsplit_selfp, singlephase.py:322-330)
@@ -151,7 +152,7 @@ void pc_setup(tp_ctx *c) {
         if (c->spbuf.n < (size_t)10 * c->g.ntot) c->spbuf.alloc((size_t)10 * c->g.ntot);
         Sl.base = c->spbuf.p;                  // S7, filled by selfp_build on the stream of the S set-up below
         Sl.slot_stride = c->g.ntot;
-    } else if (cptr && c->opt.schur_a11) {
+    } else if (cptr && (c->opt.schur_a11 || c->opt.fs_additive)) {
         // pc_fieldsplit_schur_precondition a11 (singlephase.py:331-338, twophase.py:598-616): the T-T block of the
         // (decoupled) primary system stands in for the Schur complement
         Sl.base = c->opA00.base + 3 * (c->opA01.base - c->opA00.base);     // block (1,1) = 3 planes after (0,0)
@@ -265,11 +266,16 @@ void stage1_apply(tp_ctx *c, const double *x, double *y, bool zero_secondary) {
             Stencil A10, A01;
             A10.base = c->gA10.p; A10.slot_stride = ng;
             A01.base = c->gA01.p; A01.slot_stride = ng;
+            if (c->opt.fs_additive) {               // PCFIELDSPLIT additive: one V-cycle per field
+                amg_vcycle(c, c->amg_p, gr0, gy0);
+                amg_vcycle(c, c->amg_T, gr1, gy1);
+            } else {
             amg_vcycle(c, c->amg_p, gr0, gw);
             spmv_scalar(c, G, A10, gw, gt, -1.0, gr1);
             amg_vcycle(c, c->amg_T, gt, gy1);
             spmv_scalar(c, G, A01, gy1, gt, -1.0, gr0);
             amg_vcycle(c, c->amg_p, gt, gy0);
+            }
         }
         // my slab of the result INCLUDING its halo planes (global planes lo-1 .. hi), so y needs no exchange
         const long off = g.np * c->grid.off2;
@@ -284,6 +290,11 @@ void stage1_apply(tp_ctx *c, const double *x, double *y, bool zero_secondary) {
     // PCFIELDSPLIT schur FULL on (p,T) (twophase.py:536-545): K(A00), K(S~) = one V-cycle each
     // (multi-GPU with distributed AMG levels: the V-cycles return owned cells, the couplings read halos)
     double *y0 = y, *y1 = y + nt;
+    if (c->opt.fs_additive) {              // PCFIELDSPLIT additive (pc_fieldsplit_diag, singlephase.py:371-375)
+        amg_vcycle(c, c->amg_p, r0, y0);
+        amg_vcycle(c, c->amg_T, r1, y1);
+        return;
+    }
     amg_vcycle(c, c->amg_p, r0, c->w4.p);                                   // y0 = K(A00) r0
     if (c->dist) halo_exchange(c, g, c->w4.p, 1, nt);
     spmv_scalar(c, g, c->opA10, c->w4.p, t, -1.0, r1);                      // t = r1 - A10 y0
@@ -318,7 +329,7 @@ static void pc_apply_body(tp_ctx *c, const double *x, double *y) {
 void pc_apply(tp_ctx *c, const double *x, double *y) {
     TP_REQUIRE(c->pc_ready, "pc_apply before pc_setup");
     static const bool use_graph = !(getenv("TP_GRAPH") && atoi(getenv("TP_GRAPH")) == 0);
-    c->vcycles += c->opt.pc_kind == 4 ? 0 : schur_of(c->opt) ? 3 : 1;
+    c->vcycles += c->opt.pc_kind == 4 ? 0 : c->opt.fs_additive ? 2 : schur_of(c->opt) ? 3 : 1;
     ensure_work(c);                      // never allocate inside a stream capture
     resolve_cycle_shapes(c);             // (waits for the last set-up's dominance ratios: not inside a capture either)
     if (!use_graph || c->dist) {

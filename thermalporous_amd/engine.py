@@ -46,7 +46,7 @@ class tp_options(C.Structure):
                 ("ilu_t1", C.c_int32), ("ilu_t2", C.c_int32), ("ilu_t0", C.c_int32),
                 ("amg_full_levels", C.c_int32), ("amg_coarse_pre", C.c_int32), ("amg_coarse_post", C.c_int32),
                 ("amg_mid_skip", C.c_int32), ("amg_tail_post", C.c_int32), ("amg_single", C.c_int32), ("schur_a11", C.c_int32), ("amg_gather_cells", C.c_int32), ("amg_dom_tau", C.c_double),
-                ("ilu_levels", C.c_int32)]
+                ("ilu_levels", C.c_int32), ("fs_additive", C.c_int32)]
 
 
 class tp_solve_info(C.Structure):
@@ -74,6 +74,7 @@ DEFAULT_OPTS = dict(
     amg_dom_tau=0.25,       # relaxation-only truncation of diagonally dominant AMG hierarchies (oracle/linalg.py:SemiAMG)
     amg_gather_cells=2000000,
     schur_a11=False,
+    fs_additive=False,      # pc_fieldsplit_type additive on (p,T): pc_fieldsplit_diag (singlephase.py:371-375)
     schur_selfp=False,      # pc_fieldsplit_schur_precondition selfp (pc_fieldsplit_selfp, singlephase.py:322-330)
     ilu_tile=None,          # None: whole axis-0 lines x 8 x 8 columns (3-D), x 32 columns (2-D); see default_ilu_tile
     ilu_levels=0,           # sub_1_sub_pc_factor_levels: 0 (block-ILU(0)) or 1 (block-ILU(1), pc_cprilu1_gmres)
@@ -252,7 +253,7 @@ class HipEngine:
                           o["amg_omega"], o["amg_nu"], o["amg_min_cells"], int(min(t[1], 64)), int(min(t[2], 64)),
                           0 if t[0] >= (1 << 30) else int(t[0]), int(o["amg_full_levels"]), int(o["amg_coarse_pre"]),
                           int(o["amg_coarse_post"]), int(bool(o["amg_mid_skip"])), int(o["amg_tail_post"]), int(bool(o["amg_single"])), 2 if o.get("schur_selfp") else int(bool(o["schur_a11"])),
-                          int(o["amg_gather_cells"]), float(o.get("amg_dom_tau", 0.0)), int(o.get("ilu_levels", 0)))
+                          int(o["amg_gather_cells"]), float(o.get("amg_dom_tau", 0.0)), int(o.get("ilu_levels", 0)), int(bool(o.get("fs_additive", False))))
 
     def set_options(self, **kw):
         self.opts.update(kw)

@@ -83,7 +83,9 @@ class SinglePhase(ThermalModel):
                              "fieldsplit_1": v_cycle}
         pc_fieldsplit_selfp = {**pc_fieldsplit_a11,      # (:322-330) Sp = A_TT - A_Tp diag(A_pp)^-1 A_pT
                                "pc_fieldsplit_schur_precondition": "selfp"}
-        presets = {"pc_fieldsplit_a11": pc_fieldsplit_a11, "pc_fieldsplit_selfp": pc_fieldsplit_selfp, "pc_cpr": pc_cpr,
+        pc_fieldsplit_diag = {"pc_type": "fieldsplit", "pc_fieldsplit_type": "additive",       # (:371-375)
+                              "fieldsplit_0": v_cycle, "fieldsplit_1": v_cycle}
+        presets = {"pc_fieldsplit_diag": pc_fieldsplit_diag, "pc_fieldsplit_a11": pc_fieldsplit_a11, "pc_fieldsplit_selfp": pc_fieldsplit_selfp, "pc_cpr": pc_cpr,
                    "pc_cpr_QI": {**pc_cpr, "sub_0_cpr_decoup": "QI"},      # (:353)
                    "pc_cpr_TI": {**pc_cpr, "sub_0_cpr_decoup": "TI"},      # (:354)
                    "pc_bilu": {"pc_type": "bjacobi", "sub_pc_type": "ilu", "sub_pc_factor_levels": 1, "mat_type": "aij"},   # (402-406)

@@ -78,13 +78,14 @@ def _flatten(d, prefix=""):
     return out
 
 
-def engine_options(solver_parameters, model_name, decoup="No"):
+def engine_options(solver_parameters, model_name, decoup="No", vector=False):
     from .engine import DEFAULT_OPTS
     sp = _flatten(dict(solver_parameters))
     o = dict(DEFAULT_OPTS)
     o["decoup"] = decoup
     o["schur_a11"] = False
     o["schur_selfp"] = False
+    o["fs_additive"] = False
     used = set()
     build_keys = ("amg_omega", "amg_nu", "amg_min_cells", "amg_full_levels", "amg_coarse_pre", "amg_coarse_post", "amg_mid_skip", "amg_tail_post", "amg_single",
                   "amg_gather_cells", "amg_dom_tau", "ilu_tile", "ilu_levels")
@@ -135,7 +136,15 @@ def engine_options(solver_parameters, model_name, decoup="No"):
         # pc_fieldsplit_cd (singlephase.py:309-319): Schur FULL on (p,T), V-cycle on A_pp, ConvDiffSchurPC on S;
         # pc_fieldsplit_a11 (:331-338): A_TT stands in for the Schur complement;
         # pc_fieldsplit_selfp (:322-330): Sp = A_TT - A_Tp diag(A_pp)^-1 A_pT
-        _take(sp, used, "pc_fieldsplit_type", ("schur",))
+        if _take(sp, used, "pc_fieldsplit_type", ("schur", "additive")) == "additive":
+            # pc_fieldsplit_diag (singlephase.py:371-375): block-diagonal, one V-cycle on A_pp and one on A_TT
+            _take_vcycle(sp, "fieldsplit_0_", used)
+            _take_vcycle(sp, "fieldsplit_1_", used)
+            if model_name == "Two-phase" or o["decoup"] != "No":
+                raise NotImplementedError("pc_fieldsplit_diag is a single-phase preconditioner without decoupling")
+            o["pc"], o["schur_a11"], o["fs_additive"] = "fieldsplit_cd", True, True
+            _reject_unused(sp, used)
+            return o
         fact = str(_take(sp, used, "pc_fieldsplit_schur_fact_type", None, "")).upper()
         pre = _take(sp, used, "pc_fieldsplit_schur_precondition", ("a11", "selfp"))
         if "pc_fieldsplit_type" not in used or fact != "FULL":
@@ -194,9 +203,14 @@ def engine_options(solver_parameters, model_name, decoup="No"):
         first = _take(sp, used, "sub_0_fieldsplit_0_pc_type", ("hypre", "fieldsplit"))
         if first == "hypre":
             if f0 != "0":
-                raise NotImplementedError("system AMG on several fields (pc_cptramg_gmres) is not on the hot path")
+                raise NotImplementedError("one AMG V-cycle on an explicit multi-field split is not on the hot path")
             _take_vcycle(sp, "sub_0_fieldsplit_0_", used)
-            o["pc"] = "cpr"
+            if model_name == "Two-phase" and vector and "sub_0_pc_fieldsplit_0_fields" not in used:
+                # pc_cptramg_gmres (twophase.py:698-713): no explicit fields, so with vector=True (forced at :953-955) the
+                # splits are the function space's own sub-spaces: (p,T) interleaved | S_o -- ONE V-cycle on the (p,T) system
+                o["pc"] = "cptramg"
+            else:
+                o["pc"] = "cpr"
         elif first == "fieldsplit":
             _take(sp, used, "sub_0_fieldsplit_0_pc_fieldsplit_type", ("schur",))
             fact = str(_take(sp, used, "sub_0_fieldsplit_0_pc_fieldsplit_schur_fact_type", None, "")).upper()

@@ -98,7 +98,7 @@ class ThermalModel:
         self.F = "DG0/TPFA residual assembled on the device (csrc/tp_assembly.hip)"
 
     def init_solver(self):
-        self.engine_opts = engine_options(self.solver_parameters, self.name, self.decoup)
+        self.engine_opts = engine_options(self.solver_parameters, self.name, self.decoup, vector=bool(getattr(self, "vector", False)))
         factory = getattr(self, "_engine_factory", None)
         if factory is None:
             from .engine import HipEngine

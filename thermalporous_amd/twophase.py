@@ -145,6 +145,8 @@ class TwoPhase(ThermalModel):
                    "pc_cpr_gmres": pc_cpr_gmres, "pc_cptr_gmres": pc_cptr_gmres,
                    "pc_cprilu1_gmres": {**pc_cpr_gmres, "sub_1_sub_pc_factor_levels": 1},     # (:653-668) block-ILU(1) second stage
                    "pc_bilu": {"pc_type": "bjacobi", "sub_pc_type": "ilu", "sub_pc_factor_levels": 1, "mat_type": "aij"},   # (758-762)
+                   "pc_cptramg_gmres": {k: v for k, v in pc_cpr_gmres.items()                    # (:698-713) pure-PETSc emulation
+                                        if k not in ("sub_0_pc_fieldsplit_0_fields", "sub_0_pc_fieldsplit_1_fields")},
                    "pc_cptramg": pc_cptramg,                                           # (:552-563)
                    "pc_cptramg_QI": {**pc_cptramg, "sub_0_cpr_decoup": "QI"},        # (:565)
                    "pc_cptramg_TI": {**pc_cptramg, "sub_0_cpr_decoup": "TI"}}        # (:566)
