@@ -305,6 +305,31 @@ def main():
                     break
         except (OSError, KeyError, ValueError):
             pass
+    # algorithmic bytes of ONE Krylov iteration (SURVEY.md 8d figures): block SpMV + ILU application (same bytes) + the
+    # inter-stage residual on the primary columns + classical Gram-Schmidt at the average basis size + the V-cycles of
+    # stage 1 (4.5 x 104 B x operator complexity per full cycle; a relaxation-only cycle = 2 sweeps of 104 B)
+    pc = eng.opts["pc"]
+    npri = 1 if pc == "cpr" else 2
+    k_avg = 0.5*(lits/max(nits, 1) + 1.0)
+    it_bytes = {"spmv": SPMV_BYTES_PER_CELL[key], "gram_schmidt": (2.0*k_avg + 3.0)*eng.b*8}
+    if pc != "fieldsplit_cd":
+        it_bytes["ilu_sweeps"] = SPMV_BYTES_PER_CELL[key]
+        it_bytes["stage_residual"] = SPMV_BYTES_PER_CELL[key]*npri/eng.b
+    vc = 0.0
+    for which, count in ((0, 2 if pc in ("cptr", "fieldsplit_cd") else 1), (1, 1 if pc in ("cptr", "fieldsplit_cd") else 0)):
+        if count:
+            try:
+                _, oc = eng.amg_info(which)
+                tr, _ = eng.amg_trunc(which)
+                vc += count*(2*104.0 if tr == 0 else 4.5*104.0*oc)
+            except Exception:
+                pass
+    it_bytes["vcycles"] = vc
+    it_total = float(sum(it_bytes.values()))
+    whole = {"bytes_per_cell": it_total, "breakdown": it_bytes, "ms": it_ms,
+             "achieved_GBs": it_total*ncell_local/(it_ms*1e-3)/1e9, "frac": it_total*ncell_local/(it_ms*1e-3)/1e9/HBM_PEAK_GBS,
+             "note": "algorithmic bytes of one FGMRES iteration / wall time per iteration of the timed region (everything "
+                     "included: Newton overheads, host syncs, failed solves); the honest figure for the latency-bound 2-D configs"}
     desc = CONFIGS[args.config][0]
     out = {
         "metric": "Newton steps/s, SPE10 60x220x85 two-phase (FGMRES its/s in config)" if args.config == "c4"
@@ -338,7 +363,8 @@ def main():
         "roofline": {"bound": "hbm", "achieved": ilu["achieved_GBs"], "peak": HBM_PEAK_GBS, "unit": "GB/s",
                      "frac": ilu["frac"], "traffic": traffic,
                      "kernel": "k_ilu_solve<%d>" % eng.b, "bytes_per_cell": ilu["bytes_per_cell"],
-                     "cells_per_launch": ncell_local, "avg_ms": ilu["avg_ms"], "other_kernels": others},
+                     "cells_per_launch": ncell_local, "avg_ms": ilu["avg_ms"], "other_kernels": others,
+                     "whole_iteration": whole},
     }
     if want_cpu:
         try:
