@@ -23,6 +23,7 @@ for tile in [None] + tiles:
         t0 = time.perf_counter()
         r = e.newton_solve()
         wall = time.perf_counter() - t0
+    e._ck(e.lib.tp_jacobian(e.ctx)); e.pc_setup()
     print(json.dumps(dict(levels=e.opts.get("ilu_levels", 0), tile=[min(t, 9999) for t in e.opts["ilu_tile"]], nits=r["nits"], lits=r["lits"], reason=r["reason"], solve_ms=round(wall*1e3, 1),
                           ilu_solve_ms=round(e.time_kernel(1, 50), 4), pc_apply_ms=round(e.time_kernel(4, 20), 4), ilu_factor_ms=round(e.time_kernel(6, 10), 4))), flush=True)
     e.close()
