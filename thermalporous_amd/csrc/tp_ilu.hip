@@ -26,6 +26,15 @@
 #include "tp_common.hpp"
 #include <cstdlib>
 
+// compact chunk rows are padded to this many lanes: 8 lanes x 16 B = one 128-byte line, so that a row never straddles
+// a line shared with its neighbour row (a 54-lane row of 864 B touches 8 lines where 7 would do)
+#ifndef ILU_ROW_ALIGN
+#define ILU_ROW_ALIGN 1
+#endif
+#ifndef TP_ILU_UNROLL
+#define TP_ILU_UNROLL 4
+#endif
+
 namespace tp {
 
 template <int B>
@@ -59,6 +68,9 @@ __device__ __forceinline__ void inv_block<3>(const double (&A)[3][3], double (&I
 struct IluGeom {
     GridDev g;
     int t0, t1, t2, nt0, nt1, nt2, nsteps;
+    int ntiles;    // nt0*nt1*nt2
+    int smajor;    // 1: chunks stored step-major, [step][tile] -- all tiles sweep in lockstep, so at any moment the chip reads
+                   //    ONE contiguous region (DRAM pages stay open) instead of one distant stream per tile
     int nl;        // lanes of a wave that carry a column: t1*t2 <= 64
     int rs;        // doubles per chunk row: 2*nl when the rows are as wide as the tile (CP kernels), else 128
 };
@@ -73,6 +85,10 @@ template <int B> struct IluLayout {
     static constexpr int NEJ = 7 * B * B;                 // Jacobian entries per cell (7 blocks)
     static constexpr int PJ = (NEJ + 1) / 2;              // pairs per chunk of the re-ordered Jacobian
 };
+
+__device__ __forceinline__ long chunk_idx(const IluGeom &G, int tile, int s) {
+    return G.smajor ? (long)s * G.ntiles + tile : (long)tile * G.nsteps + s;
+}
 
 // tile/lane/step -> cell; returns false if the lane has no cell at this step
 struct TileInfo {
@@ -137,11 +153,13 @@ __global__ __launch_bounds__(64 * ILU_SEG) void k_ilu_gather(IluGeom G, const do
         double2 o;
         o.x = v[2 * u];
         o.y = v[2 * u + 1];
-        if (!CP || lane < NL) reinterpret_cast<double2 *>(Jt + (((long)tile * ns + s) * L::PJ + P0 + u) * RS)[lane] = o;
+        if (!CP || lane < NL) reinterpret_cast<double2 *>(Jt + (chunk_idx(G, tile, s) * L::PJ + P0 + u) * RS)[lane] = o;
     }
 }
 
-template <int B, bool CP>
+// MW: the factor is written in the layout of the multi-wave sweep (k_ilu_solve_mw): one run of doubles per block ROW,
+// [tile][step][row r][entry (a, q)][lane] -- forward 3B entries per row (B_a[r][q]), backward 4B (C_a[r][q], then D~^-1[r][q])
+template <int B, bool CP, bool MW>
 __global__ __launch_bounds__(64) void k_ilu_factor(IluGeom G, const double *__restrict__ Jt, double *fwd,
                                                    double *bwd) {
     using L = IluLayout<B>;
@@ -179,11 +197,11 @@ __global__ __launch_bounds__(64) void k_ilu_factor(IluGeom G, const double *__re
         int l0;
         long c;
         k.ok = tile_cell(G, ti, s, l0, c);
-        const double2 *ch = reinterpret_cast<const double2 *>(Jt + ((long)tile * ns + s) * ((long)L::PJ * RS)) + la;
+        const double2 *ch = reinterpret_cast<const double2 *>(Jt + chunk_idx(G, tile, s) * ((long)L::PJ * RS)) + la;
         double v[2 * L::PJ];
 #pragma unroll
         for (int p = 0; p < L::PJ; ++p) {
-            const double2 t = ch[p * NL];
+            const double2 t = ch[p * (RS >> 1)];
             v[2 * p] = t.x;
             v[2 * p + 1] = t.y;
         }
@@ -220,8 +238,14 @@ __global__ __launch_bounds__(64) void k_ilu_factor(IluGeom G, const double *__re
                 Amc[2][r][q] = __shfl_up(Aprev[2][r][q], G.t1, 64);
             }
         double D[B][B], Di[B][B];
-        double *fch = fwd + ((long)tile * ns + s) * ((long)L::PF * RS);
-        double *bch = bwd + ((long)tile * ns + s) * ((long)L::PB * RS);
+        constexpr int PFR = (3 * B + 1) / 2, PBR = (4 * B + 1) / 2;       // (IluMwLayout)
+        double *fch = fwd + chunk_idx(G, tile, s) * (MW ? (long)2 * B * PFR * G.nl : (long)L::PF * RS);
+        double *bch = bwd + chunk_idx(G, tile, s) * (MW ? (long)2 * B * PBR * G.nl : (long)L::PB * RS);
+        const bool mlive = lane < G.nl;
+        auto fidx = [&](int a, int r, int q) { return MW ? ((long)(r * PFR + ((a * B + q) >> 1)) * G.nl + lane) * 2 + ((a * B + q) & 1)
+                                                         : (long)((((a * B + r) * B + q) >> 1) * RS + lane * 2 + (((a * B + r) * B + q) & 1)); };
+        auto bidx = [&](int a, int r, int q) { return MW ? ((long)(r * PBR + ((a * B + q) >> 1)) * G.nl + lane) * 2 + ((a * B + q) & 1)
+                                                         : (long)((((a * B + r) * B + q) >> 1) * RS + lane * 2 + (((a * B + r) * B + q) & 1)); };
 #pragma unroll
         for (int r = 0; r < B; ++r)
 #pragma unroll
@@ -246,11 +270,10 @@ __global__ __launch_bounds__(64) void k_ilu_factor(IluGeom G, const double *__re
 #pragma unroll
                     for (int t = 0; t < B; ++t) v += Bm[r][t] * Amc[a][t][q];
                     D[r][q] -= v;
-                    const int e = (a * B + r) * B + q;
-                    if (live) fch[(e >> 1) * RS + lane * 2 + (e & 1)] = Bm[r][q];
+                    if (MW ? mlive : live) fch[fidx(a, r, q)] = Bm[r][q];
                 }
         }
-        if ((L::NEF & 1) && live) fch[(L::NEF >> 1) * RS + lane * 2 + 1] = 0.0;    // padding half of the last pair
+        if (!MW && (L::NEF & 1) && live) fch[(L::NEF >> 1) * RS + lane * 2 + 1] = 0.0;    // padding half of the last pair
         if (k.ok) {
             inv_block<B>(D, Di);
         } else {
@@ -269,15 +292,13 @@ __global__ __launch_bounds__(64) void k_ilu_factor(IluGeom G, const double *__re
                     double v = 0.0;
 #pragma unroll
                     for (int t = 0; t < B; ++t) v += Di[r][t] * k.Aup[a][t][q];
-                    const int e = (a * B + r) * B + q;
-                    if (live) bch[(e >> 1) * RS + lane * 2 + (e & 1)] = v;
+                    if (MW ? mlive : live) bch[bidx(a, r, q)] = v;
                 }
 #pragma unroll
         for (int r = 0; r < B; ++r)
 #pragma unroll
             for (int q = 0; q < B; ++q) {
-                const int e = (3 * B + r) * B + q;
-                if (live) bch[(e >> 1) * RS + lane * 2 + (e & 1)] = Di[r][q];
+                if (MW ? mlive : live) bch[bidx(3, r, q)] = Di[r][q];
                 Dp[r][q] = Di[r][q];
             }
 #pragma unroll
@@ -329,11 +350,11 @@ __global__ __launch_bounds__(64) void k_ilu_solve(IluGeom G, const double *__res
     const bool live = CP ? lane < NL : true;                     // (compile-time true with wave-wide rows: see k_ilu_factor)
     const long nt = G.g.ntot;
     const TileInfo ti = tile_info(G, tile, lane);
-    const long chunk0 = (long)tile * G.nsteps;
     const int ns = G.nsteps;
     const long rowF = (long)L::PF * RS, rowB = (long)L::PB * RS, rowY = (long)L::PY * RS;
     const long park = min((long)lane, G.g.np - 1);     // an entry of the lower halo plane: where cell-less lanes read / write
     constexpr int RING = DEPTH2 ? 3 : 2;
+    constexpr int UN = TP_ILU_UNROLL;          // rings per steady-state loop iteration
     int l0;
     long c;
     // ---- forward: y_c = r_c - sum_lower B_cm y_m -------------------------------------------------
@@ -346,7 +367,7 @@ __global__ __launch_bounds__(64) void k_ilu_solve(IluGeom G, const double *__res
         bool okk[RING];
         auto load = [&](int k, int step) {
             okk[k] = tile_cell(G, ti, step, l0, c);
-            load_chunk<L::PF>(fwd + (chunk0 + step) * rowF, la, NL, buf[k]);
+            load_chunk<L::PF>(fwd + chunk_idx(G, tile, step) * rowF, la, RS >> 1, buf[k]);
             // BRANCH-FREE: a lane without a cell at this step reads entry `lane` of the lower halo plane (valid memory,
             // finite) and the value is dropped by a select.  A load or store behind a divergent branch makes the compiler
             // drain every outstanding load (s_waitcnt vmcnt(0)) at each step, prefetch ring included.
@@ -370,8 +391,8 @@ __global__ __launch_bounds__(64) void k_ilu_solve(IluGeom G, const double *__res
                 for (int r = 0; r < B; ++r)
 #pragma unroll
                     for (int q = 0; q < B; ++q) y[r] -= chunk_get<L::PF>(buf[k], (a * B + r) * B + q) * yn[a][q];
-            double *ych = ytmp + (chunk0 + s) * rowY;
-            const long ydump = ((long)G.nsteps * gridDim.x - (chunk0 + s)) * rowY + ((long)tile * 64 + lane) * B;
+            double *ych = ytmp + chunk_idx(G, tile, s) * rowY;
+            const long ydump = ((long)G.nsteps * gridDim.x - chunk_idx(G, tile, s)) * rowY + ((long)tile * 64 + lane) * B;
 #pragma unroll
             for (int r = 0; r < B; ++r) {
                 y[r] = okk[k] ? y[r] : 0.0;
@@ -384,7 +405,19 @@ __global__ __launch_bounds__(64) void k_ilu_solve(IluGeom G, const double *__res
         for (int k = 0; k < RING; ++k)
             if (k < ns) load(k, k);
         int s = 0;
-        for (; s + 2 * RING <= ns; s += RING) {          // steady state: no condition inside the body
+        // The compiler drains every outstanding load (s_waitcnt vmcnt(0)) at a loop header whose back edge carries
+        // loads in flight: one exposed memory latency per loop iteration.  UN rings per iteration make that one per
+        // UN*RING steps instead of one per RING.
+        for (; s + (UN + 1) * RING <= ns; s += UN * RING) {      // steady state: no condition inside the body
+#pragma unroll
+            for (int u = 0; u < UN; ++u)
+#pragma unroll
+                for (int k = 0; k < RING; ++k) {
+                    step(k, s + u * RING + k);
+                    load(k, s + u * RING + k + RING);
+                }
+        }
+        for (; s + 2 * RING <= ns; s += RING) {
 #pragma unroll
             for (int k = 0; k < RING; ++k) {
                 step(k, s + k);
@@ -422,8 +455,8 @@ __global__ __launch_bounds__(64) void k_ilu_solve(IluGeom G, const double *__res
         auto load = [&](int k, int step) {
             okk[k] = tile_cell(G, ti, step, l0, c);
             cc[k] = c;
-            load_chunk<L::PB>(bwd + (chunk0 + step) * rowB, la, NL, buf[k]);
-            if (!YLDS) load_chunk<(YLDS ? 1 : L::PY)>(ytmp + (chunk0 + step) * rowY, la, NL, ybuf[k]);
+            load_chunk<L::PB>(bwd + chunk_idx(G, tile, step) * rowB, la, RS >> 1, buf[k]);
+            if (!YLDS) load_chunk<(YLDS ? 1 : L::PY)>(ytmp + chunk_idx(G, tile, step) * rowY, la, RS >> 1, ybuf[k]);
             const long cs = okk[k] ? c : park;                // branch-free, as in the forward sweep
 #pragma unroll
             for (int r = 0; r < B; ++r) aa[k][r] = asrc[r][cs];
@@ -465,7 +498,16 @@ __global__ __launch_bounds__(64) void k_ilu_solve(IluGeom G, const double *__res
         for (int k = 0; k < RING; ++k)
             if (ns - 1 - k >= 0) load(k, ns - 1 - k);
         int s = ns - 1;
-        for (; s - 2 * RING + 1 >= 0; s -= RING) {       // steady state: no condition inside the body
+        for (; s - (UN + 1) * RING + 1 >= 0; s -= UN * RING) {   // steady state: no condition inside the body
+#pragma unroll
+            for (int u = 0; u < UN; ++u)
+#pragma unroll
+                for (int k = 0; k < RING; ++k) {
+                    step(k, s - u * RING - k);
+                    load(k, s - u * RING - k - RING);
+                }
+        }
+        for (; s - 2 * RING + 1 >= 0; s -= RING) {
 #pragma unroll
             for (int k = 0; k < RING; ++k) {
                 step(k, s - k);
@@ -478,6 +520,215 @@ __global__ __launch_bounds__(64) void k_ilu_solve(IluGeom G, const double *__res
                 if (s - k >= 0) {
                     step(k, s - k);
                     if (s - k - RING >= 0) load(k, s - k - RING);
+                }
+            }
+        }
+    }
+}
+
+// ---------------------------------------------------------------------------------------------------------------
+// Multi-wave sweep: B wavefronts per tile, wave r computes block ROW r of every step (field r of y and x).  The serial
+// recurrence of a step -- what bounds the one-wave kernel above: ~130 dependent instructions per step issued by a single
+// wave -- is cut to 3B loads, 3B FMAs and one LDS exchange per wave: the fields of a step's result go through the LDS
+// (where the intermediate vector y lives anyway), one s_barrier per step; neighbours' values are LDS reads at
+// lane-1 / lane-t1 (clamped: the coefficient of a neighbour that does not exist is zero) instead of shuffles.
+// The barrier orders LDS accesses only (workgroup-scope fences restricted to the local address space + s_barrier):
+// __syncthreads() would also drain the prefetched global loads.
+// LDS: y of every step when it fits (YLDS), else a two-step ring (y then goes through HBM for the backward sweep).
+#define TP_LDS_BARRIER()                                                        \
+    do {                                                                        \
+        __builtin_amdgcn_fence(__ATOMIC_RELEASE, "workgroup", "local");         \
+        __builtin_amdgcn_s_barrier();                                           \
+        __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "workgroup", "local");         \
+    } while (0)
+template <int B> struct IluMwLayout {
+    static constexpr int PFR = (3 * B + 1) / 2;      // double2 pairs per forward row: B_a[r][q], a = 0..2 (+ padding half)
+    static constexpr int PBR = (4 * B + 1) / 2;      // pairs per backward row: C_a[r][q], a = 0..2, then D~^-1[r][q]
+};
+
+// grid layout <-> chunk order of the tiles.  Like k_ilu_gather: a workgroup covers ILU_SEG consecutive steps of one tile,
+// so the 16 doubles of every grid-layout cache line it touches are consumed (or produced) inside the workgroup; the chunk
+// side is coalesced.  Thousands of waves: the per-lane cache-line transactions that serialise inside a tile's sweep are
+// spread over the whole chip here.
+template <int B>
+__global__ __launch_bounds__(64 * ILU_SEG) void k_ilu_pack(IluGeom G, const double *__restrict__ src, double *__restrict__ dst) {
+    const int tile = blockIdx.x, s = blockIdx.y * ILU_SEG + (threadIdx.x >> 6), lane = threadIdx.x & 63;
+    if (s >= G.nsteps || lane >= G.nl) return;
+    const TileInfo ti = tile_info(G, tile, lane);
+    int l0;
+    long c;
+    if (!tile_cell(G, ti, s, l0, c)) return;          // (positions without a cell keep their zeros)
+    const long slot = chunk_idx(G, tile, s) * B;
+#pragma unroll
+    for (int r = 0; r < B; ++r) dst[(slot + r) * (long)G.nl + lane] = src[(long)r * G.g.ntot + c];
+}
+template <int B>
+__global__ __launch_bounds__(64 * ILU_SEG) void k_ilu_unpack(IluGeom G, const double *__restrict__ xpk, const double *addto,
+                                                             int nadd, double *x) {
+    const int tile = blockIdx.x, s = blockIdx.y * ILU_SEG + (threadIdx.x >> 6), lane = threadIdx.x & 63;
+    if (s >= G.nsteps || lane >= G.nl) return;
+    const TileInfo ti = tile_info(G, tile, lane);
+    int l0;
+    long c;
+    if (!tile_cell(G, ti, s, l0, c)) return;
+    const long slot = chunk_idx(G, tile, s) * B;
+#pragma unroll
+    for (int r = 0; r < B; ++r) {
+        const double a = (addto && r < nadd) ? addto[(long)r * G.g.ntot + c] : 0.0;
+        x[(long)r * G.g.ntot + c] = a + xpk[(slot + r) * (long)G.nl + lane];
+    }
+}
+
+// PK: the right-hand side comes, and the result goes, in the tile's chunk order ([chunk][field][lane]: k_ilu_pack /
+// k_ilu_unpack): in the grid layout the lanes of a wave sit n0 doubles apart, so every vector load or store of the sweep
+// touches one cache line PER LANE -- 54 line transactions per instruction on C4, 9 such instructions per step in the
+// serial chain of a tile (measured: 0.065 of the sweep's 0.185 ms).  Many-wave kernels do that transposition for free.
+template <int B, bool YLDS, bool PK>
+__global__ __launch_bounds__(64 * B) void k_ilu_solve_mw(IluGeom G, const double *__restrict__ fwd,
+                                                         const double *__restrict__ bwd, const double *__restrict__ rhs,
+                                                         double *__restrict__ ytmp, double *x, const double *addto, int nadd) {
+    extern __shared__ double lds[];
+    using M = IluMwLayout<B>;
+    // ring depths: a wave may have 63 loads in flight; what the sweep's throughput follows is BYTES in flight per CU
+    // (B waves x ring x 16-byte loads: 3 x 8 x 6 x 864 B = 124 KB on C4, against 44 KB for the one-wave kernel)
+    constexpr int RF = 8, RB = YLDS ? 8 : 6;
+    const int tile = blockIdx.x, lane = threadIdx.x & 63, r = threadIdx.x >> 6;
+    const int NL = G.nl, ns = G.nsteps;
+    const int la = min(lane, NL - 1);                 // idle lanes shadow the last live lane's loads ...
+    const bool live = lane < NL;                      // ... and store to dump locations: no divergent branch in the loops
+    const long nt = G.g.ntot;
+    const TileInfo ti = tile_info(G, tile, la);
+    const long park = min((long)lane, G.g.np - 1);
+    const int lm1 = max(la - 1, 0), lmt = max(la - G.t1, 0), lp1 = min(la + 1, NL - 1), lpt = min(la + G.t1, NL - 1);
+    const int slotsz = B * NL;
+    double *yl = lds;                                  // slot s+1 holds y of step s (slot 0 = zeros); ring of 2 without YLDS
+    double *xl = lds + (size_t)(YLDS ? ns + 1 : 2) * slotsz;      // two slots, by step parity
+    double *ldump = xl + 2 * slotsz + threadIdx.x;     // where idle lanes store
+    double *gdump = ytmp + (long)gridDim.x * ns * slotsz + (long)tile * 64 * B + threadIdx.x;
+    for (int i = threadIdx.x; i < slotsz; i += 64 * B) { yl[i] = 0.0; xl[i] = 0.0; xl[slotsz + i] = 0.0; }
+    TP_LDS_BARRIER();
+    int l0;
+    long c;
+    // ---- forward: y_c[r] = rhs_c[r] - sum_a B_a[r][:] y_(m_a) ------------------------------------------------------
+    {
+        double2 v[RF][M::PFR];
+        double rr[RF];
+        bool okk[RF];
+        auto load = [&](int k, int s) {
+            okk[k] = tile_cell(G, ti, s, l0, c) && live;
+            const double2 *ch = reinterpret_cast<const double2 *>(fwd + (chunk_idx(G, tile, s) * B + r) * (long)(2 * M::PFR * NL)) + la;
+#pragma unroll
+            for (int p = 0; p < M::PFR; ++p) v[k][p] = ch[(long)p * NL];
+            rr[k] = PK ? rhs[(chunk_idx(G, tile, s) * B + r) * (long)NL + la] : rhs[(long)r * nt + (okk[k] ? c : park)];
+        };
+        auto step = [&](int k, int s) {
+            const double *yp = yl + (size_t)(YLDS ? s : (s & 1)) * slotsz;      // y of step s-1
+            double acc[3];
+#pragma unroll
+            for (int a = 0; a < 3; ++a) {
+                const int src = a == 0 ? la : a == 1 ? lm1 : lmt;
+                double t = 0.0;
+#pragma unroll
+                for (int q = 0; q < B; ++q) t += chunk_get<M::PFR>(v[k], a * B + q) * yp[q * NL + src];
+                acc[a] = t;
+            }
+            // (a 0/1 factor, not a select: the compiler turns `ok ? expr : 0` into a branch around the LDS reads, and a
+            // divergent branch makes it drain the prefetched loads at every step)
+            const double y = (okk[k] ? 1.0 : 0.0) * (rr[k] - (acc[0] + acc[1] + acc[2]));
+            double *dst = yl + (size_t)(YLDS ? s + 1 : ((s + 1) & 1)) * slotsz + r * NL + lane;
+            *(live ? dst : ldump) = y;
+            if (!YLDS) *(live ? ytmp + (chunk_idx(G, tile, s) * B + r) * (long)NL + lane : gdump) = y;
+            TP_LDS_BARRIER();
+        };
+#pragma unroll
+        for (int k = 0; k < RF; ++k)
+            if (k < ns) load(k, k);
+        int s = 0;
+        for (; s + 2 * RF <= ns; s += RF) {              // steady state: no condition inside the body
+#pragma unroll
+            for (int k = 0; k < RF; ++k) {
+                step(k, s + k);
+                load(k, s + k + RF);
+            }
+        }
+        for (; s < ns; s += RF) {
+#pragma unroll
+            for (int k = 0; k < RF; ++k) {
+                if (s + k < ns) {
+                    step(k, s + k);
+                    if (s + k + RF < ns) load(k, s + k + RF);
+                }
+            }
+        }
+    }
+    // ---- backward: x_c[r] = D~^-1[r][:] y_c - sum_a C_a[r][:] x_(m_a) -------------------------------------------------
+    {
+        double2 v[RB][M::PBR];
+        double yb[RB][YLDS ? 1 : B], aa[RB];
+        bool okk[RB];
+        long cc[RB];
+        const bool use = addto && r < nadd;
+        const double *asrc = (use ? addto : rhs) + (long)r * nt;
+        const double amask = use ? 1.0 : 0.0;
+        auto load = [&](int k, int s) {
+            okk[k] = tile_cell(G, ti, s, l0, c) && live;
+            cc[k] = okk[k] ? c : park;
+            const double2 *ch = reinterpret_cast<const double2 *>(bwd + (chunk_idx(G, tile, s) * B + r) * (long)(2 * M::PBR * NL)) + la;
+#pragma unroll
+            for (int p = 0; p < M::PBR; ++p) v[k][p] = ch[(long)p * NL];
+            if (!YLDS) {
+#pragma unroll
+                for (int q = 0; q < B; ++q) yb[k][q] = ytmp[(chunk_idx(G, tile, s) * B + q) * (long)NL + la];
+            }
+            aa[k] = PK ? 0.0 : asrc[cc[k]];
+        };
+        auto step = [&](int k, int s) {
+            const double *xp = xl + (size_t)((s + 1) & 1) * slotsz;             // x of step s+1
+            const double *yv = yl + (size_t)(s + 1) * slotsz;                   // (YLDS only)
+            double t = 0.0;
+#pragma unroll
+            for (int q = 0; q < B; ++q) t += chunk_get<M::PBR>(v[k], 3 * B + q) * (YLDS ? yv[q * NL + la] : yb[k][q]);
+            double acc[3];
+#pragma unroll
+            for (int a = 0; a < 3; ++a) {
+                const int src = a == 0 ? la : a == 1 ? lp1 : lpt;
+                double u = 0.0;
+#pragma unroll
+                for (int q = 0; q < B; ++q) u += chunk_get<M::PBR>(v[k], a * B + q) * xp[q * NL + src];
+                acc[a] = u;
+            }
+            const double xv = (okk[k] ? 1.0 : 0.0) * (t - (acc[0] + acc[1] + acc[2]));
+            double *dst = xl + (size_t)(s & 1) * slotsz + r * NL + lane;
+            *(live ? dst : ldump) = xv;
+            if (PK) {
+                double *gx = x + (chunk_idx(G, tile, s) * B + r) * (long)NL + lane;
+                *(live ? gx : gdump) = xv;
+            } else {
+                // lanes without a cell write 0.0 to an entry of x's lower halo plane (as the one-wave sweep does)
+                x[(long)r * nt + cc[k]] = (okk[k] ? 1.0 : 0.0) * (amask * aa[k] + xv);
+            }
+            TP_LDS_BARRIER();
+        };
+        // (without YLDS the forward sweep's y stores of the last steps may still be in flight: every wave re-reads values
+        // written by OTHER waves of the workgroup, so drain them and make them visible first)
+        if (!YLDS) { __threadfence_block(); __syncthreads(); }
+#pragma unroll
+        for (int k = 0; k < RB; ++k)
+            if (ns - 1 - k >= 0) load(k, ns - 1 - k);
+        int s = ns - 1;
+        for (; s - 2 * RB + 1 >= 0; s -= RB) {           // steady state
+#pragma unroll
+            for (int k = 0; k < RB; ++k) {
+                step(k, s - k);
+                load(k, s - k - RB);
+            }
+        }
+        for (; s >= 0; s -= RB) {
+#pragma unroll
+            for (int k = 0; k < RB; ++k) {
+                if (s - k >= 0) {
+                    step(k, s - k);
+                    if (s - k - RB >= 0) load(k, s - k - RB);
                 }
             }
         }
@@ -784,15 +1035,19 @@ static IluGeom geom_of(const tp_ctx *c) {
     G.nt0 = c->ilu.nt0; G.nt1 = c->ilu.nt1; G.nt2 = c->ilu.nt2;
     G.nsteps = c->ilu.nsteps;
     G.nl = G.t1 * G.t2;
-    G.rs = ilu_compact(c) ? 2 * G.nl : 128;
+    G.ntiles = c->ilu.ntiles;
+    static const bool smajor = !(getenv("TP_ILU_SMAJOR") && atoi(getenv("TP_ILU_SMAJOR")) == 0);
+    G.smajor = (smajor && c->ilu.levels == 0) ? 1 : 0;
+    G.rs = ilu_compact(c) ? 2 * ((G.nl + ILU_ROW_ALIGN - 1) / ILU_ROW_ALIGN * ILU_ROW_ALIGN) : 128;
     return G;
 }
 
 template <int B>
 static void alloc_factor(IluData &d, bool compact) {
     using L = IluLayout<B>;
-    const size_t chunks = (size_t)d.ntiles * d.nsteps, rs = compact ? (size_t)2 * d.t1 * d.t2 : 128;
-    d.fwd.alloc(chunks * L::PF * rs);
+    const size_t chunks = (size_t)d.ntiles * d.nsteps,
+                 rs = compact ? (size_t)2 * ((d.t1 * d.t2 + ILU_ROW_ALIGN - 1) / ILU_ROW_ALIGN * ILU_ROW_ALIGN) : 128;
+    d.fwd.alloc(chunks * std::max((size_t)L::PF * rs, (size_t)B * ((3 * B + 1) / 2) * 2 * d.t1 * d.t2));   // (multi-wave layout: padded rows)
     d.bwd.alloc(chunks * L::PB * rs);
     d.ytmp.alloc(chunks * L::PY * rs + (size_t)d.ntiles * 64 * B);     // + parking slots of idle lanes (branch-free stores)
     d.jt.alloc(chunks * L::PJ * rs);
@@ -817,6 +1072,8 @@ void ilu_setup(tp_ctx *c) {
     d.ntiles = d.nt0 * d.nt1 * d.nt2;
     TP_REQUIRE(c->opt.ilu_levels == 0 || c->opt.ilu_levels == 1, "ilu_levels must be 0 or 1");
     d.levels = c->opt.ilu_levels;
+    static const bool mw_on = !(getenv("TP_ILU_MW") && atoi(getenv("TP_ILU_MW")) == 0);
+    d.mw = mw_on && d.levels == 0;
     d.nsteps = d.levels ? t0 + 2 * (t1 - 1) + 4 * (t2 - 1) : t0 + t1 + t2 - 2;
     d.slots = (long)d.ntiles * d.nsteps * 64;
     c->graph_epoch++;            // new tile layout / factor buffers: captured pc_apply graphs are stale
@@ -829,6 +1086,15 @@ void ilu_setup(tp_ctx *c) {
         return;
     }
     if (c->b == 3) alloc_factor<3>(d, ilu_compact(c)); else alloc_factor<2>(d, ilu_compact(c));
+    static const bool pk_on = getenv("TP_ILU_PACK") && atoi(getenv("TP_ILU_PACK")) == 1;
+    if (d.mw && pk_on) {
+        const size_t pkn = (size_t)d.ntiles * d.nsteps * c->b * d.t1 * d.t2;
+        d.rpk.alloc(pkn);
+        d.xpk.alloc(pkn);
+    } else {
+        d.rpk.free();
+        d.xpk.free();
+    }
 }
 
 void ilu_factor(tp_ctx *c) {
@@ -849,8 +1115,10 @@ void ilu_factor(tp_ctx *c) {
     do {                                                                                                               \
         hipLaunchKernelGGL((k_ilu_gather<BB, CC>), dim3(c->ilu.ntiles, (IluLayout<BB>::PJ + ILU_PPT - 1) / ILU_PPT, nseg), \
                            dim3(64 * ILU_SEG), 0, c->stream, G, c->J.p, c->ilu.jt.p);                                   \
-        hipLaunchKernelGGL((k_ilu_factor<BB, CC>), dim3(c->ilu.ntiles), dim3(64), 0, c->stream, G, c->ilu.jt.p,        \
-                           c->ilu.fwd.p, c->ilu.bwd.p);                                                                \
+        if (c->ilu.mw) hipLaunchKernelGGL((k_ilu_factor<BB, CC, true>), dim3(c->ilu.ntiles), dim3(64), 0, c->stream, G,   \
+                                          c->ilu.jt.p, c->ilu.fwd.p, c->ilu.bwd.p);                                      \
+        else hipLaunchKernelGGL((k_ilu_factor<BB, CC, false>), dim3(c->ilu.ntiles), dim3(64), 0, c->stream, G, c->ilu.jt.p, \
+                                c->ilu.fwd.p, c->ilu.bwd.p);                                                           \
     } while (0)
     if (c->b == 3) { if (cp) TP_ILU_FACTOR(3, true); else TP_ILU_FACTOR(3, false); }
     else           { if (cp) TP_ILU_FACTOR(2, true); else TP_ILU_FACTOR(2, false); }
@@ -883,6 +1151,41 @@ void ilu_solve(tp_ctx *c, const double *r, double *x, const double *addto, int n
     if (c->ilu.levels) {
         if (c->b == 3) hipLaunchKernelGGL((k_ilu1_solve<3>), dim3(c->ilu.ntiles), dim3(64), 0, c->stream, G, c->ilu.fwd.p, c->ilu.bwd.p, r, c->ilu.ytmp.p, x, addto, nadd);
         else           hipLaunchKernelGGL((k_ilu1_solve<2>), dim3(c->ilu.ntiles), dim3(64), 0, c->stream, G, c->ilu.fwd.p, c->ilu.bwd.p, r, c->ilu.ytmp.p, x, addto, nadd);
+        TP_HIP(hipGetLastError());
+        return;
+    }
+    if (c->ilu.mw) {
+        const size_t slot = (size_t)c->b * G.nl * sizeof(double);
+        const size_t dump = (size_t)64 * c->b * sizeof(double);            // where idle lanes store
+        const size_t full = ((size_t)G.nsteps + 1 + 2) * slot + dump, ring = 4 * slot + dump;
+        static const bool ylds_mw = !(getenv("TP_ILU_YLDS") && atoi(getenv("TP_ILU_YLDS")) == 0);
+        const bool yl = ylds_mw && full <= 156 * 1024;
+        const bool pk_on = c->ilu.rpk.n > 0;             // (allocated by ilu_setup: never inside a stream capture)
+#define TP_ILU_MW_LAUNCH(BB, YY)                                                                                        \
+        do {                                                                                                            \
+            static bool attr_set = false;                                                                               \
+            if (!attr_set) {                                                                                            \
+                TP_HIP(hipFuncSetAttribute(reinterpret_cast<const void *>(&k_ilu_solve_mw<BB, YY, false>),              \
+                                           hipFuncAttributeMaxDynamicSharedMemorySize, 156 * 1024));                    \
+                TP_HIP(hipFuncSetAttribute(reinterpret_cast<const void *>(&k_ilu_solve_mw<BB, YY, true>),               \
+                                           hipFuncAttributeMaxDynamicSharedMemorySize, 156 * 1024));                    \
+                attr_set = true;                                                                                        \
+            }                                                                                                           \
+            if (pk_on) {                                                                                                \
+                hipLaunchKernelGGL((k_ilu_pack<BB>), dim3(c->ilu.ntiles, (G.nsteps + ILU_SEG - 1) / ILU_SEG), dim3(64 * ILU_SEG), 0, c->stream, G, r, c->ilu.rpk.p);   \
+                hipLaunchKernelGGL((k_ilu_solve_mw<BB, YY, true>), dim3(c->ilu.ntiles), dim3(64 * BB), YY ? full : ring, \
+                                   c->stream, G, c->ilu.fwd.p, c->ilu.bwd.p, c->ilu.rpk.p, c->ilu.ytmp.p, c->ilu.xpk.p, \
+                                   nullptr, 0);                                                                         \
+                hipLaunchKernelGGL((k_ilu_unpack<BB>), dim3(c->ilu.ntiles, (G.nsteps + ILU_SEG - 1) / ILU_SEG), dim3(64 * ILU_SEG), 0, c->stream, G, c->ilu.xpk.p,     \
+                                   addto, nadd, x);                                                                     \
+            } else {                                                                                                    \
+                hipLaunchKernelGGL((k_ilu_solve_mw<BB, YY, false>), dim3(c->ilu.ntiles), dim3(64 * BB), YY ? full : ring, \
+                                   c->stream, G, c->ilu.fwd.p, c->ilu.bwd.p, r, c->ilu.ytmp.p, x, addto, nadd);         \
+            }                                                                                                           \
+        } while (0)
+        if (c->b == 3) { if (yl) TP_ILU_MW_LAUNCH(3, true); else TP_ILU_MW_LAUNCH(3, false); }
+        else           { if (yl) TP_ILU_MW_LAUNCH(2, true); else TP_ILU_MW_LAUNCH(2, false); }
+#undef TP_ILU_MW_LAUNCH
         TP_HIP(hipGetLastError());
         return;
     }
