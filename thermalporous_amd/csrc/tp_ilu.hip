@@ -1036,7 +1036,7 @@ static IluGeom geom_of(const tp_ctx *c) {
     G.nsteps = c->ilu.nsteps;
     G.nl = G.t1 * G.t2;
     G.ntiles = c->ilu.ntiles;
-    static const bool smajor = !(getenv("TP_ILU_SMAJOR") && atoi(getenv("TP_ILU_SMAJOR")) == 0);
+    static const bool smajor = getenv("TP_ILU_SMAJOR") && atoi(getenv("TP_ILU_SMAJOR")) == 1;      // (measured neutral: off)
     G.smajor = (smajor && c->ilu.levels == 0) ? 1 : 0;
     G.rs = ilu_compact(c) ? 2 * ((G.nl + ILU_ROW_ALIGN - 1) / ILU_ROW_ALIGN * ILU_ROW_ALIGN) : 128;
     return G;
