@@ -546,36 +546,43 @@ template <int B> struct IluMwLayout {
     static constexpr int PBR = (4 * B + 1) / 2;      // pairs per backward row: C_a[r][q], a = 0..2, then D~^-1[r][q]
 };
 
-// grid layout <-> chunk order of the tiles.  Like k_ilu_gather: a workgroup covers ILU_SEG consecutive steps of one tile,
-// so the 16 doubles of every grid-layout cache line it touches are consumed (or produced) inside the workgroup; the chunk
-// side is coalesced.  Thousands of waves: the per-lane cache-line transactions that serialise inside a tile's sweep are
-// spread over the whole chip here.
-template <int B>
-__global__ __launch_bounds__(64 * ILU_SEG) void k_ilu_pack(IluGeom G, const double *__restrict__ src, double *__restrict__ dst) {
-    const int tile = blockIdx.x, s = blockIdx.y * ILU_SEG + (threadIdx.x >> 6), lane = threadIdx.x & 63;
-    if (s >= G.nsteps || lane >= G.nl) return;
-    const TileInfo ti = tile_info(G, tile, lane);
-    int l0;
-    long c;
-    if (!tile_cell(G, ti, s, l0, c)) return;          // (positions without a cell keep their zeros)
-    const long slot = chunk_idx(G, tile, s) * B;
-#pragma unroll
-    for (int r = 0; r < B; ++r) dst[(slot + r) * (long)G.nl + lane] = src[(long)r * G.g.ntot + c];
-}
-template <int B>
-__global__ __launch_bounds__(64 * ILU_SEG) void k_ilu_unpack(IluGeom G, const double *__restrict__ xpk, const double *addto,
-                                                             int nadd, double *x) {
-    const int tile = blockIdx.x, s = blockIdx.y * ILU_SEG + (threadIdx.x >> 6), lane = threadIdx.x & 63;
-    if (s >= G.nsteps || lane >= G.nl) return;
-    const TileInfo ti = tile_info(G, tile, lane);
-    int l0;
-    long c;
-    if (!tile_cell(G, ti, s, l0, c)) return;
-    const long slot = chunk_idx(G, tile, s) * B;
-#pragma unroll
-    for (int r = 0; r < B; ++r) {
-        const double a = (addto && r < nadd) ? addto[(long)r * G.g.ntot + c] : 0.0;
-        x[(long)r * G.g.ntot + c] = a + xpk[(slot + r) * (long)G.nl + lane];
+// grid layout <-> chunk order of the tiles ([chunk][field][lane]; tile-major chunks: ILU_SEG consecutive steps of a tile
+// are ONE contiguous run).  A workgroup transposes one such run through the LDS: the chunk side is a contiguous copy, the
+// grid side moves, per column (j,k) of the tile, the ILU_SEG cells l0 = s - j - k of those steps -- contiguous doubles --
+// with lanes along l0: 4 columns = 4..8 cache lines per wave instruction instead of one line per lane.
+template <int B, bool PACK>
+__global__ __launch_bounds__(256) void k_ilu_transpose(IluGeom G, const double *__restrict__ grid_in, double *__restrict__ grid_out,
+                                                       const double *__restrict__ chunk_in, double *__restrict__ chunk_out,
+                                                       const double *addto, int nadd) {
+    extern __shared__ double tbuf[];                  // [step][field][lane]
+    const int tile = blockIdx.x, s0 = blockIdx.y * ILU_SEG, NL = G.nl;
+    const int nseg = min(ILU_SEG, G.nsteps - s0);
+    const int run = nseg * B * NL;
+    const long base = chunk_idx(G, tile, s0) * (long)(B * NL);
+    const long nt = G.g.ntot;
+    const int T0 = tile % G.nt0, T1 = (tile / G.nt0) % G.nt1, T2 = tile / (G.nt0 * G.nt1);
+    const int b0 = T0 * G.t0, b1 = T1 * G.t1, b2 = T2 * G.t2;
+    const int tt0 = min(G.t0, G.g.n0 - b0), tj = min(G.t1, G.g.n1 - b1), tk = min(G.t2, G.g.n2 - b2);
+    if (!PACK) {
+        for (int i = threadIdx.x; i < run; i += 256) tbuf[i] = chunk_in[base + i];
+        __syncthreads();
+    }
+    for (int i = threadIdx.x; i < B * NL * ILU_SEG; i += 256) {
+        const int m = i % ILU_SEG, col = (i / ILU_SEG) % NL, r = i / (ILU_SEG * NL);
+        const int j = col % G.t1, k = col / G.t1;
+        const int l0 = s0 + m - j - k;
+        const bool ok = m < nseg && j < tj && k < tk && l0 >= 0 && l0 < tt0;
+        const long c = G.g.np + (long)(b0 + l0) + (long)G.g.n0 * (b1 + j) + G.g.np * (b2 + k);
+        if (PACK) {
+            if (m < nseg) tbuf[(m * B + r) * NL + col] = ok ? grid_in[(long)r * nt + c] : 0.0;
+        } else if (ok) {
+            const double a = (addto && r < nadd) ? addto[(long)r * nt + c] : 0.0;
+            grid_out[(long)r * nt + c] = a + tbuf[(m * B + r) * NL + col];
+        }
+    }
+    if (PACK) {
+        __syncthreads();
+        for (int i = threadIdx.x; i < run; i += 256) chunk_out[base + i] = tbuf[i];
     }
 }
 
@@ -1086,7 +1093,10 @@ void ilu_setup(tp_ctx *c) {
         return;
     }
     if (c->b == 3) alloc_factor<3>(d, ilu_compact(c)); else alloc_factor<2>(d, ilu_compact(c));
-    static const bool pk_on = getenv("TP_ILU_PACK") && atoi(getenv("TP_ILU_PACK")) == 1;
+    // chunk-ordered right-hand side / solution (k_ilu_transpose before and after the sweep): pays when several tiles share
+    // a CU -- C5 slab, 1088 tiles: sweep 1.56 -> 1.36 ms -- and costs two launches otherwise (C4, 250 tiles: 0.187 vs 0.188 ms;
+    // the 2-D configurations +30 %); TP_ILU_PACK=0/1 forces it
+    const bool pk_on = getenv("TP_ILU_PACK") ? atoi(getenv("TP_ILU_PACK")) == 1 : d.ntiles >= 512;
     if (d.mw && pk_on) {
         const size_t pkn = (size_t)d.ntiles * d.nsteps * c->b * d.t1 * d.t2;
         d.rpk.alloc(pkn);
@@ -1161,6 +1171,8 @@ void ilu_solve(tp_ctx *c, const double *r, double *x, const double *addto, int n
         static const bool ylds_mw = !(getenv("TP_ILU_YLDS") && atoi(getenv("TP_ILU_YLDS")) == 0);
         const bool yl = ylds_mw && full <= 156 * 1024;
         const bool pk_on = c->ilu.rpk.n > 0;             // (allocated by ilu_setup: never inside a stream capture)
+        const size_t tbytes = (size_t)ILU_SEG * c->b * G.nl * sizeof(double);
+        TP_REQUIRE(!pk_on || !G.smajor, "TP_ILU_PACK needs tile-major chunks");
 #define TP_ILU_MW_LAUNCH(BB, YY)                                                                                        \
         do {                                                                                                            \
             static bool attr_set = false;                                                                               \
@@ -1172,12 +1184,13 @@ void ilu_solve(tp_ctx *c, const double *r, double *x, const double *addto, int n
                 attr_set = true;                                                                                        \
             }                                                                                                           \
             if (pk_on) {                                                                                                \
-                hipLaunchKernelGGL((k_ilu_pack<BB>), dim3(c->ilu.ntiles, (G.nsteps + ILU_SEG - 1) / ILU_SEG), dim3(64 * ILU_SEG), 0, c->stream, G, r, c->ilu.rpk.p);   \
+                hipLaunchKernelGGL((k_ilu_transpose<BB, true>), dim3(c->ilu.ntiles, (G.nsteps + ILU_SEG - 1) / ILU_SEG),    \
+                                   dim3(256), tbytes, c->stream, G, r, nullptr, nullptr, c->ilu.rpk.p, nullptr, 0);      \
                 hipLaunchKernelGGL((k_ilu_solve_mw<BB, YY, true>), dim3(c->ilu.ntiles), dim3(64 * BB), YY ? full : ring, \
                                    c->stream, G, c->ilu.fwd.p, c->ilu.bwd.p, c->ilu.rpk.p, c->ilu.ytmp.p, c->ilu.xpk.p, \
                                    nullptr, 0);                                                                         \
-                hipLaunchKernelGGL((k_ilu_unpack<BB>), dim3(c->ilu.ntiles, (G.nsteps + ILU_SEG - 1) / ILU_SEG), dim3(64 * ILU_SEG), 0, c->stream, G, c->ilu.xpk.p,     \
-                                   addto, nadd, x);                                                                     \
+                hipLaunchKernelGGL((k_ilu_transpose<BB, false>), dim3(c->ilu.ntiles, (G.nsteps + ILU_SEG - 1) / ILU_SEG),   \
+                                   dim3(256), tbytes, c->stream, G, nullptr, x, c->ilu.xpk.p, nullptr, addto, nadd);     \
             } else {                                                                                                    \
                 hipLaunchKernelGGL((k_ilu_solve_mw<BB, YY, false>), dim3(c->ilu.ntiles), dim3(64 * BB), YY ? full : ring, \
                                    c->stream, G, c->ilu.fwd.p, c->ilu.bwd.p, r, c->ilu.ytmp.p, x, addto, nadd);         \
