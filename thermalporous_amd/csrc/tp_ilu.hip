@@ -558,13 +558,18 @@ __global__ __launch_bounds__(256) void k_ilu_transpose(IluGeom G, const double *
     const int tile = blockIdx.x, s0 = blockIdx.y * ILU_SEG, NL = G.nl;
     const int nseg = min(ILU_SEG, G.nsteps - s0);
     const int run = nseg * B * NL;
-    const long base = chunk_idx(G, tile, s0) * (long)(B * NL);
     const long nt = G.g.ntot;
     const int T0 = tile % G.nt0, T1 = (tile / G.nt0) % G.nt1, T2 = tile / (G.nt0 * G.nt1);
     const int b0 = T0 * G.t0, b1 = T1 * G.t1, b2 = T2 * G.t2;
     const int tt0 = min(G.t0, G.g.n0 - b0), tj = min(G.t1, G.g.n1 - b1), tk = min(G.t2, G.g.n2 - b2);
     if (!PACK) {
-        for (int i = threadIdx.x; i < run; i += 256) tbuf[i] = chunk_in[base + i];
+        if (!G.smajor) {                              // tile-major: the ILU_SEG chunks are one contiguous run
+            const long base = chunk_idx(G, tile, s0) * (long)(B * NL);
+            for (int i = threadIdx.x; i < run; i += 256) tbuf[i] = chunk_in[base + i];
+        } else {
+            for (int i = threadIdx.x; i < run; i += 256)
+                tbuf[i] = chunk_in[chunk_idx(G, tile, s0 + i / (B * NL)) * (long)(B * NL) + i % (B * NL)];
+        }
         __syncthreads();
     }
     for (int i = threadIdx.x; i < B * NL * ILU_SEG; i += 256) {
@@ -582,7 +587,13 @@ __global__ __launch_bounds__(256) void k_ilu_transpose(IluGeom G, const double *
     }
     if (PACK) {
         __syncthreads();
-        for (int i = threadIdx.x; i < run; i += 256) chunk_out[base + i] = tbuf[i];
+        if (!G.smajor) {
+            const long base = chunk_idx(G, tile, s0) * (long)(B * NL);
+            for (int i = threadIdx.x; i < run; i += 256) chunk_out[base + i] = tbuf[i];
+        } else {
+            for (int i = threadIdx.x; i < run; i += 256)
+                chunk_out[chunk_idx(G, tile, s0 + i / (B * NL)) * (long)(B * NL) + i % (B * NL)] = tbuf[i];
+        }
     }
 }
 
@@ -1172,7 +1183,6 @@ void ilu_solve(tp_ctx *c, const double *r, double *x, const double *addto, int n
         const bool yl = ylds_mw && full <= 156 * 1024;
         const bool pk_on = c->ilu.rpk.n > 0;             // (allocated by ilu_setup: never inside a stream capture)
         const size_t tbytes = (size_t)ILU_SEG * c->b * G.nl * sizeof(double);
-        TP_REQUIRE(!pk_on || !G.smajor, "TP_ILU_PACK needs tile-major chunks");
 #define TP_ILU_MW_LAUNCH(BB, YY)                                                                                        \
         do {                                                                                                            \
             static bool attr_set = false;                                                                               \
