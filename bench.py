@@ -362,7 +362,7 @@ def main():
         },
         "roofline": {"bound": "hbm", "achieved": ilu["achieved_GBs"], "peak": HBM_PEAK_GBS, "unit": "GB/s",
                      "frac": ilu["frac"], "traffic": traffic,
-                     "kernel": "k_ilu_solve<%d>" % eng.b, "bytes_per_cell": ilu["bytes_per_cell"],
+                     "kernel": ("k_ilu_solve<%d>" if os.environ.get("TP_ILU_MW") == "0" else "k_ilu_solve_mw<%d>") % eng.b, "bytes_per_cell": ilu["bytes_per_cell"],
                      "cells_per_launch": ncell_local, "avg_ms": ilu["avg_ms"], "other_kernels": others,
                      "whole_iteration": whole},
     }
