@@ -21,6 +21,8 @@
 // application.  The chunks of the next steps are prefetched through a ring of register buffers.
 // Traffic: (3+4) b^2 doubles per cell plus vectors, that of one block SpMV.  Measured: the solve
 // moves 4.5 TB/s but is bound by the serial recurrence, not by HBM.
+// Default sweep kernel since round 2: k_ilu_solve_mw (one wavefront per block ROW of a tile, same chunk stream, same
+// schedule; DESIGN.md 4.4 vi); k_ilu_solve below is the one-wave kernel described here (TP_ILU_MW=0).
 // The factorisation reads the Jacobian through k_ilu_gather, which re-orders it into the same chunk order
 // with thousands of waves (the plane layout puts neighbouring lanes n0 doubles apart).
 #include "tp_common.hpp"
