@@ -26,6 +26,7 @@
 // The factorisation reads the Jacobian through k_ilu_gather, which re-orders it into the same chunk order
 // with thousands of waves (the plane layout puts neighbouring lanes n0 doubles apart).
 #include "tp_common.hpp"
+#include <type_traits>
 #include <cstdlib>
 
 // compact chunk rows are padded to this many lanes: 8 lanes x 16 B = one 128-byte line, so that a row never straddles
@@ -603,7 +604,11 @@ __global__ __launch_bounds__(256) void k_ilu_transpose(IluGeom G, const double *
 // k_ilu_unpack): in the grid layout the lanes of a wave sit n0 doubles apart, so every vector load or store of the sweep
 // touches one cache line PER LANE -- 54 line transactions per instruction on C4, 9 such instructions per step in the
 // serial chain of a tile (measured: 0.065 of the sweep's 0.185 ms).  Many-wave kernels do that transposition for free.
-template <int B, bool YLDS, bool PK>
+// (The lambdas are force-inlined: left to its heuristics the compiler outlines them in the larger instantiations, the
+// register arrays they capture by reference then live in scratch memory, and the sweep is ten times slower.)
+// BLK: grid-layout vectors moved in blocks of RF / RB steps (below); off for the short 2-D tiles, where the delayed block stores
+// only lengthen the tail
+template <int B, bool YLDS, bool PK, bool BLK>
 __global__ __launch_bounds__(64 * B) void k_ilu_solve_mw(IluGeom G, const double *__restrict__ fwd,
                                                          const double *__restrict__ bwd, const double *__restrict__ rhs,
                                                          double *__restrict__ ytmp, double *x, const double *addto, int nadd) {
@@ -632,16 +637,27 @@ __global__ __launch_bounds__(64 * B) void k_ilu_solve_mw(IluGeom G, const double
     // ---- forward: y_c[r] = rhs_c[r] - sum_a B_a[r][:] y_(m_a) ------------------------------------------------------
     {
         double2 v[RF][M::PFR];
-        double rr[RF];
+        double rr[RF], rrA[RF], rrB[RF];
         bool okk[RF];
-        auto load = [&](int k, int s) {
+        // Right-hand side in the grid layout: a lane's cells of consecutive steps are consecutive doubles of ITS column, but
+        // the lanes of a wave sit n0 doubles apart -- one cache line per lane.  Loaded one value per step, every line is
+        // fetched from L2 sixteen times (the CU's L1 does not hold the ~270 lines the three waves touch per step until the
+        // next step).  Loaded RF values at a time, back to back, it is fetched twice: blocks of RF steps, double buffered.
+        const long cb = G.g.np + (long)ti.base0 + (long)G.g.n0 * (ti.base1 + ti.j) + G.g.np * (ti.base2 + ti.k) - (ti.j + ti.k);
+        auto blockload = [&](double (&dst)[RF], int s) __attribute__((always_inline)) {      // values of steps s .. s+RF-1 (addresses clamped: unused ones are masked)
+            const double *col = rhs + (long)r * nt;
+#pragma unroll
+            for (int q = 0; q < RF; ++q) dst[q] = col[min(max(cb + s + q, 0L), nt - 1)];
+        };
+        auto load = [&](int k, int s) __attribute__((always_inline)) {
             okk[k] = tile_cell(G, ti, s, l0, c) && live;
             const double2 *ch = reinterpret_cast<const double2 *>(fwd + (chunk_idx(G, tile, s) * B + r) * (long)(2 * M::PFR * NL)) + la;
 #pragma unroll
             for (int p = 0; p < M::PFR; ++p) v[k][p] = ch[(long)p * NL];
-            rr[k] = PK ? rhs[(chunk_idx(G, tile, s) * B + r) * (long)NL + la] : rhs[(long)r * nt + (okk[k] ? c : park)];
+            if (PK) rr[k] = rhs[(chunk_idx(G, tile, s) * B + r) * (long)NL + la];
+            else if (!BLK) rr[k] = rhs[(long)r * nt + (okk[k] ? c : park)];
         };
-        auto step = [&](int k, int s) {
+        auto step = [&](int k, int s, double rhs_k) __attribute__((always_inline)) {
             const double *yp = yl + (size_t)(YLDS ? s : (s & 1)) * slotsz;      // y of step s-1
             double acc[3];
 #pragma unroll
@@ -654,45 +670,55 @@ __global__ __launch_bounds__(64 * B) void k_ilu_solve_mw(IluGeom G, const double
             }
             // (a 0/1 factor, not a select: the compiler turns `ok ? expr : 0` into a branch around the LDS reads, and a
             // divergent branch makes it drain the prefetched loads at every step)
-            const double y = (okk[k] ? 1.0 : 0.0) * (rr[k] - (acc[0] + acc[1] + acc[2]));
+            const double y = (okk[k] ? 1.0 : 0.0) * (((PK || !BLK) ? rr[k] : rhs_k) - (acc[0] + acc[1] + acc[2]));
             double *dst = yl + (size_t)(YLDS ? s + 1 : ((s + 1) & 1)) * slotsz + r * NL + lane;
             *(live ? dst : ldump) = y;
             if (!YLDS) *(live ? ytmp + (chunk_idx(G, tile, s) * B + r) * (long)NL + lane : gdump) = y;
             TP_LDS_BARRIER();
         };
+        // RF steps on the values of `cur`, with the block of the following RF steps loaded into `nxt` first
+        auto half = [&](double (&cur)[RF], double (&nxt)[RF], int s, auto guarded) __attribute__((always_inline)) {
+            if (BLK && !PK) blockload(nxt, s + RF);
+#pragma unroll
+            for (int k = 0; k < RF; ++k) {
+                if (!decltype(guarded)::value || s + k < ns) {
+                    step(k, s + k, cur[k]);
+                    if (!decltype(guarded)::value || s + k + RF < ns) load(k, s + k + RF);
+                }
+            }
+        };
+        if (BLK && !PK) blockload(rrA, 0);
 #pragma unroll
         for (int k = 0; k < RF; ++k)
             if (k < ns) load(k, k);
         int s = 0;
-        for (; s + 2 * RF <= ns; s += RF) {              // steady state: no condition inside the body
-#pragma unroll
-            for (int k = 0; k < RF; ++k) {
-                step(k, s + k);
-                load(k, s + k + RF);
-            }
+        for (; s + 3 * RF <= ns; s += 2 * RF) {          // steady state: no condition inside the body
+            half(rrA, rrB, s, std::false_type{});
+            half(rrB, rrA, s + RF, std::false_type{});
         }
-        for (; s < ns; s += RF) {
-#pragma unroll
-            for (int k = 0; k < RF; ++k) {
-                if (s + k < ns) {
-                    step(k, s + k);
-                    if (s + k + RF < ns) load(k, s + k + RF);
-                }
-            }
+        for (; s < ns; s += 2 * RF) {
+            half(rrA, rrB, s, std::true_type{});
+            if (s + RF < ns) half(rrB, rrA, s + RF, std::true_type{});
         }
     }
-    // ---- backward: x_c[r] = D~^-1[r][:] y_c - sum_a C_a[r][:] x_(m_a) -------------------------------------------------
+// ---- backward: x_c[r] = D~^-1[r][:] y_c - sum_a C_a[r][:] x_(m_a) -------------------------------------------------
     {
         double2 v[RB][M::PBR];
-        double yb[RB][YLDS ? 1 : B], aa[RB];
+        double yb[RB][YLDS ? 1 : B], aA[RB], aB[RB], xq[RB], aa[RB];
         bool okk[RB];
         long cc[RB];
         const bool use = addto && r < nadd;
         const double *asrc = (use ? addto : rhs) + (long)r * nt;
         const double amask = use ? 1.0 : 0.0;
-        auto load = [&](int k, int s) {
+        const long cb = G.g.np + (long)ti.base0 + (long)G.g.n0 * (ti.base1 + ti.j) + G.g.np * (ti.base2 + ti.k) - (ti.j + ti.k);
+        // `addto` in blocks of RB steps, like the right-hand side of the forward sweep; the RB results of a block are stored
+        // back to back at its end (x may alias addto: a block's loads are all issued before the stores of the block before)
+        auto blockload = [&](double (&dst)[RB], int s) __attribute__((always_inline)) {      // values of steps s, s-1, .., s-RB+1
+#pragma unroll
+            for (int q = 0; q < RB; ++q) dst[q] = asrc[min(max(cb + s - q, 0L), nt - 1)];
+        };
+        auto load = [&](int k, int s) __attribute__((always_inline)) {
             okk[k] = tile_cell(G, ti, s, l0, c) && live;
-            cc[k] = okk[k] ? c : park;
             const double2 *ch = reinterpret_cast<const double2 *>(bwd + (chunk_idx(G, tile, s) * B + r) * (long)(2 * M::PBR * NL)) + la;
 #pragma unroll
             for (int p = 0; p < M::PBR; ++p) v[k][p] = ch[(long)p * NL];
@@ -700,9 +726,9 @@ __global__ __launch_bounds__(64 * B) void k_ilu_solve_mw(IluGeom G, const double
 #pragma unroll
                 for (int q = 0; q < B; ++q) yb[k][q] = ytmp[(chunk_idx(G, tile, s) * B + q) * (long)NL + la];
             }
-            aa[k] = PK ? 0.0 : asrc[cc[k]];
+            if (!BLK && !PK) { cc[k] = okk[k] ? c : park; aa[k] = asrc[cc[k]]; }
         };
-        auto step = [&](int k, int s) {
+        auto step = [&](int k, int s) __attribute__((always_inline)) {
             const double *xp = xl + (size_t)((s + 1) & 1) * slotsz;             // x of step s+1
             const double *yv = yl + (size_t)(s + 1) * slotsz;                   // (YLDS only)
             double t = 0.0;
@@ -723,34 +749,47 @@ __global__ __launch_bounds__(64 * B) void k_ilu_solve_mw(IluGeom G, const double
             if (PK) {
                 double *gx = x + (chunk_idx(G, tile, s) * B + r) * (long)NL + lane;
                 *(live ? gx : gdump) = xv;
-            } else {
-                // lanes without a cell write 0.0 to an entry of x's lower halo plane (as the one-wave sweep does)
-                x[(long)r * nt + cc[k]] = (okk[k] ? 1.0 : 0.0) * (amask * aa[k] + xv);
             }
+            if (!BLK && !PK) x[(long)r * nt + cc[k]] = (okk[k] ? 1.0 : 0.0) * (amask * aa[k] + xv);
+            xq[k] = xv;
             TP_LDS_BARRIER();
+        };
+        // RB steps with the addto values of `cur`, the block of the following RB steps loaded into `nxt` first
+        auto half = [&](double (&cur)[RB], double (&nxt)[RB], int s, auto guarded) __attribute__((always_inline)) {
+            bool okq[RB];
+            if (BLK && !PK) blockload(nxt, s - RB);
+#pragma unroll
+            for (int k = 0; k < RB; ++k) {
+                okq[k] = false;
+                if (!decltype(guarded)::value || s - k >= 0) {
+                    okq[k] = okk[k];
+                    step(k, s - k);
+                    if (!decltype(guarded)::value || s - k - RB >= 0) load(k, s - k - RB);
+                }
+            }
+            if (BLK && !PK) {
+                // lanes without a cell write 0.0 to an entry of x's lower halo plane (as the one-wave sweep does)
+#pragma unroll
+                for (int k = 0; k < RB; ++k)
+                    if (!decltype(guarded)::value || s - k >= 0)
+                        x[(long)r * nt + (okq[k] ? cb + s - k : park)] = (okq[k] ? 1.0 : 0.0) * (amask * cur[k] + xq[k]);
+            }
         };
         // (without YLDS the forward sweep's y stores of the last steps may still be in flight: every wave re-reads values
         // written by OTHER waves of the workgroup, so drain them and make them visible first)
         if (!YLDS) { __threadfence_block(); __syncthreads(); }
+        if (BLK && !PK) blockload(aA, ns - 1);
 #pragma unroll
         for (int k = 0; k < RB; ++k)
             if (ns - 1 - k >= 0) load(k, ns - 1 - k);
         int s = ns - 1;
-        for (; s - 2 * RB + 1 >= 0; s -= RB) {           // steady state
-#pragma unroll
-            for (int k = 0; k < RB; ++k) {
-                step(k, s - k);
-                load(k, s - k - RB);
-            }
+        for (; s - 3 * RB + 1 >= 0; s -= 2 * RB) {       // steady state
+            half(aA, aB, s, std::false_type{});
+            half(aB, aA, s - RB, std::false_type{});
         }
-        for (; s >= 0; s -= RB) {
-#pragma unroll
-            for (int k = 0; k < RB; ++k) {
-                if (s - k >= 0) {
-                    step(k, s - k);
-                    if (s - k - RB >= 0) load(k, s - k - RB);
-                }
-            }
+        for (; s >= 0; s -= 2 * RB) {
+            half(aA, aB, s, std::true_type{});
+            if (s - RB >= 0) half(aB, aA, s - RB, std::true_type{});
         }
     }
 }
@@ -1106,10 +1145,10 @@ void ilu_setup(tp_ctx *c) {
         return;
     }
     if (c->b == 3) alloc_factor<3>(d, ilu_compact(c)); else alloc_factor<2>(d, ilu_compact(c));
-    // chunk-ordered right-hand side / solution (k_ilu_transpose before and after the sweep): pays when several tiles share
-    // a CU -- C5 slab, 1088 tiles: sweep 1.56 -> 1.36 ms -- and costs two launches otherwise (C4, 250 tiles: 0.187 vs 0.188 ms;
-    // the 2-D configurations +30 %); TP_ILU_PACK=0/1 forces it
-    const bool pk_on = getenv("TP_ILU_PACK") ? atoi(getenv("TP_ILU_PACK")) == 1 : d.ntiles >= 512;
+    // chunk-ordered right-hand side / solution (k_ilu_transpose before and after the sweep; TP_ILU_PACK=1): measured
+    // against the per-step grid-layout accesses it gained 13 % on the C5 slab and nothing on C4; the block transfers of
+    // the sweep itself (BLK) do better on both (C5 slab 1.56 -> 1.27 ms, C4 0.185 -> 0.15 ms), so it is off by default
+    const bool pk_on = getenv("TP_ILU_PACK") && atoi(getenv("TP_ILU_PACK")) == 1;
     if (d.mw && pk_on) {
         const size_t pkn = (size_t)d.ntiles * d.nsteps * c->b * d.t1 * d.t2;
         d.rpk.alloc(pkn);
@@ -1185,31 +1224,38 @@ void ilu_solve(tp_ctx *c, const double *r, double *x, const double *addto, int n
         const bool yl = ylds_mw && full <= 156 * 1024;
         const bool pk_on = c->ilu.rpk.n > 0;             // (allocated by ilu_setup: never inside a stream capture)
         const size_t tbytes = (size_t)ILU_SEG * c->b * G.nl * sizeof(double);
-#define TP_ILU_MW_LAUNCH(BB, YY)                                                                                        \
+#define TP_ILU_MW_LAUNCH(BB, YY, KK)                                                                                        \
         do {                                                                                                            \
             static bool attr_set = false;                                                                               \
             if (!attr_set) {                                                                                            \
-                TP_HIP(hipFuncSetAttribute(reinterpret_cast<const void *>(&k_ilu_solve_mw<BB, YY, false>),              \
+                TP_HIP(hipFuncSetAttribute(reinterpret_cast<const void *>(&k_ilu_solve_mw<BB, YY, false, KK>),              \
                                            hipFuncAttributeMaxDynamicSharedMemorySize, 156 * 1024));                    \
-                TP_HIP(hipFuncSetAttribute(reinterpret_cast<const void *>(&k_ilu_solve_mw<BB, YY, true>),               \
+                TP_HIP(hipFuncSetAttribute(reinterpret_cast<const void *>(&k_ilu_solve_mw<BB, YY, true, KK>),               \
                                            hipFuncAttributeMaxDynamicSharedMemorySize, 156 * 1024));                    \
                 attr_set = true;                                                                                        \
             }                                                                                                           \
             if (pk_on) {                                                                                                \
                 hipLaunchKernelGGL((k_ilu_transpose<BB, true>), dim3(c->ilu.ntiles, (G.nsteps + ILU_SEG - 1) / ILU_SEG),    \
                                    dim3(256), tbytes, c->stream, G, r, nullptr, nullptr, c->ilu.rpk.p, nullptr, 0);      \
-                hipLaunchKernelGGL((k_ilu_solve_mw<BB, YY, true>), dim3(c->ilu.ntiles), dim3(64 * BB), YY ? full : ring, \
+                hipLaunchKernelGGL((k_ilu_solve_mw<BB, YY, true, KK>), dim3(c->ilu.ntiles), dim3(64 * BB), YY ? full : ring, \
                                    c->stream, G, c->ilu.fwd.p, c->ilu.bwd.p, c->ilu.rpk.p, c->ilu.ytmp.p, c->ilu.xpk.p, \
                                    nullptr, 0);                                                                         \
                 hipLaunchKernelGGL((k_ilu_transpose<BB, false>), dim3(c->ilu.ntiles, (G.nsteps + ILU_SEG - 1) / ILU_SEG),   \
                                    dim3(256), tbytes, c->stream, G, nullptr, x, c->ilu.xpk.p, nullptr, addto, nadd);     \
             } else {                                                                                                    \
-                hipLaunchKernelGGL((k_ilu_solve_mw<BB, YY, false>), dim3(c->ilu.ntiles), dim3(64 * BB), YY ? full : ring, \
+                hipLaunchKernelGGL((k_ilu_solve_mw<BB, YY, false, KK>), dim3(c->ilu.ntiles), dim3(64 * BB), YY ? full : ring, \
                                    c->stream, G, c->ilu.fwd.p, c->ilu.bwd.p, r, c->ilu.ytmp.p, x, addto, nadd);         \
             }                                                                                                           \
         } while (0)
-        if (c->b == 3) { if (yl) TP_ILU_MW_LAUNCH(3, true); else TP_ILU_MW_LAUNCH(3, false); }
-        else           { if (yl) TP_ILU_MW_LAUNCH(2, true); else TP_ILU_MW_LAUNCH(2, false); }
+        static const int blk_env = getenv("TP_ILU_BLOCK") ? atoi(getenv("TP_ILU_BLOCK")) : -1;
+        const bool blk = blk_env >= 0 ? blk_env == 1 : c->g.gn2 > 1;       // 3-D tiles: whole axis-0 lines, long sweeps
+        if (c->b == 3) {
+            if (yl) { if (blk) TP_ILU_MW_LAUNCH(3, true, true); else TP_ILU_MW_LAUNCH(3, true, false); }
+            else    { if (blk) TP_ILU_MW_LAUNCH(3, false, true); else TP_ILU_MW_LAUNCH(3, false, false); }
+        } else {
+            if (yl) { if (blk) TP_ILU_MW_LAUNCH(2, true, true); else TP_ILU_MW_LAUNCH(2, true, false); }
+            else    { if (blk) TP_ILU_MW_LAUNCH(2, false, true); else TP_ILU_MW_LAUNCH(2, false, false); }
+        }
 #undef TP_ILU_MW_LAUNCH
         TP_HIP(hipGetLastError());
         return;
