@@ -244,6 +244,23 @@ def test_bilu_preset_stage(levels, nphase):
     h.close()
 
 
+@pytest.mark.parametrize("env", [{"TP_ILU_MW": "0"}, {"TP_ILU_MW": "0", "TP_ILU_YLDS": "0"}, {"TP_ILU_BLOCK": "0"}, {"TP_ILU_BLOCK": "1"},
+                                 {"TP_ILU_YLDS": "0"}, {"TP_ILU_YLDS": "0", "TP_ILU_BLOCK": "1"}],
+                         ids=["one_wave", "one_wave_y_hbm", "mw_per_step", "mw_blocks", "mw_y_hbm", "mw_y_hbm_blocks"])
+def test_env_selected_sweep_kernels(env):
+    """The ILU(0) sweep kernels that are not the default of a given grid -- the one-wave kernel, the multi-wave kernel with /
+    without block transfers and with y through HBM -- are selected by environment variables the library reads once per
+    process: each runs tests/ilu_env_check.py (sweeps and whole preconditioner vs the oracle, 3-D and 2-D, partial tiles) in
+    ONE child process."""
+    import os
+    import subprocess
+    import sys
+    here = os.path.dirname(os.path.abspath(__file__))
+    r = subprocess.run([sys.executable, os.path.join(here, "ilu_env_check.py")], env={**os.environ, **env},
+                       capture_output=True, text=True, timeout=300)
+    assert r.returncode == 0 and r.stdout.strip().endswith("ok"), (r.stdout[-2000:], r.stderr[-2000:])
+
+
 def test_exported_vector_ops():
     """tp_vec_dot_batch / tp_vec_axpy_batch / tp_vec_norm2 (VecMDot, VecMAXPY, VecNorm of one Krylov iteration) vs numpy."""
     from thermalporous_amd.engine import HipEngine

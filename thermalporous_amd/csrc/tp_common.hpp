@@ -175,7 +175,6 @@ struct IluData {
     int t0 = 0, t1 = 8, t2 = 8, nt0 = 0, nt1 = 0, nt2 = 0, ntiles = 0, nsteps = 0;
     DBuf<double> fwd, bwd, ytmp;   // streaming factor data in consumption order
     DBuf<double> jt;               // the Jacobian blocks re-ordered the same way (input of the factorisation)
-    DBuf<double> rpk, xpk;         // right-hand side / result of a sweep in the tiles' chunk order (multi-wave sweep)
     long slots = 0;                // ntiles*nsteps*64
     bool mw = false;               // ILU(0): factor stored in the row-major layout of the multi-wave sweep (tp_ilu.hip)
     int levels = 0;                // 0: ILU(0), 1: ILU(1) (tp_options.ilu_levels; other chunk layout, see tp_ilu.hip)

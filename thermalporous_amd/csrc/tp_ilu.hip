@@ -72,8 +72,6 @@ struct IluGeom {
     GridDev g;
     int t0, t1, t2, nt0, nt1, nt2, nsteps;
     int ntiles;    // nt0*nt1*nt2
-    int smajor;    // 1: chunks stored step-major, [step][tile] -- all tiles sweep in lockstep, so at any moment the chip reads
-                   //    ONE contiguous region (DRAM pages stay open) instead of one distant stream per tile
     int nl;        // lanes of a wave that carry a column: t1*t2 <= 64
     int rs;        // doubles per chunk row: 2*nl when the rows are as wide as the tile (CP kernels), else 128
 };
@@ -90,7 +88,7 @@ template <int B> struct IluLayout {
 };
 
 __device__ __forceinline__ long chunk_idx(const IluGeom &G, int tile, int s) {
-    return G.smajor ? (long)s * G.ntiles + tile : (long)tile * G.nsteps + s;
+    return (long)tile * G.nsteps + s;      // (step-major chunks, [step][tile], were measured: no gain -- DESIGN.md 4.4 vi)
 }
 
 // tile/lane/step -> cell; returns false if the lane has no cell at this step
@@ -549,66 +547,11 @@ template <int B> struct IluMwLayout {
     static constexpr int PBR = (4 * B + 1) / 2;      // pairs per backward row: C_a[r][q], a = 0..2, then D~^-1[r][q]
 };
 
-// grid layout <-> chunk order of the tiles ([chunk][field][lane]; tile-major chunks: ILU_SEG consecutive steps of a tile
-// are ONE contiguous run).  A workgroup transposes one such run through the LDS: the chunk side is a contiguous copy, the
-// grid side moves, per column (j,k) of the tile, the ILU_SEG cells l0 = s - j - k of those steps -- contiguous doubles --
-// with lanes along l0: 4 columns = 4..8 cache lines per wave instruction instead of one line per lane.
-template <int B, bool PACK>
-__global__ __launch_bounds__(256) void k_ilu_transpose(IluGeom G, const double *__restrict__ grid_in, double *__restrict__ grid_out,
-                                                       const double *__restrict__ chunk_in, double *__restrict__ chunk_out,
-                                                       const double *addto, int nadd) {
-    extern __shared__ double tbuf[];                  // [step][field][lane]
-    const int tile = blockIdx.x, s0 = blockIdx.y * ILU_SEG, NL = G.nl;
-    const int nseg = min(ILU_SEG, G.nsteps - s0);
-    const int run = nseg * B * NL;
-    const long nt = G.g.ntot;
-    const int T0 = tile % G.nt0, T1 = (tile / G.nt0) % G.nt1, T2 = tile / (G.nt0 * G.nt1);
-    const int b0 = T0 * G.t0, b1 = T1 * G.t1, b2 = T2 * G.t2;
-    const int tt0 = min(G.t0, G.g.n0 - b0), tj = min(G.t1, G.g.n1 - b1), tk = min(G.t2, G.g.n2 - b2);
-    if (!PACK) {
-        if (!G.smajor) {                              // tile-major: the ILU_SEG chunks are one contiguous run
-            const long base = chunk_idx(G, tile, s0) * (long)(B * NL);
-            for (int i = threadIdx.x; i < run; i += 256) tbuf[i] = chunk_in[base + i];
-        } else {
-            for (int i = threadIdx.x; i < run; i += 256)
-                tbuf[i] = chunk_in[chunk_idx(G, tile, s0 + i / (B * NL)) * (long)(B * NL) + i % (B * NL)];
-        }
-        __syncthreads();
-    }
-    for (int i = threadIdx.x; i < B * NL * ILU_SEG; i += 256) {
-        const int m = i % ILU_SEG, col = (i / ILU_SEG) % NL, r = i / (ILU_SEG * NL);
-        const int j = col % G.t1, k = col / G.t1;
-        const int l0 = s0 + m - j - k;
-        const bool ok = m < nseg && j < tj && k < tk && l0 >= 0 && l0 < tt0;
-        const long c = G.g.np + (long)(b0 + l0) + (long)G.g.n0 * (b1 + j) + G.g.np * (b2 + k);
-        if (PACK) {
-            if (m < nseg) tbuf[(m * B + r) * NL + col] = ok ? grid_in[(long)r * nt + c] : 0.0;
-        } else if (ok) {
-            const double a = (addto && r < nadd) ? addto[(long)r * nt + c] : 0.0;
-            grid_out[(long)r * nt + c] = a + tbuf[(m * B + r) * NL + col];
-        }
-    }
-    if (PACK) {
-        __syncthreads();
-        if (!G.smajor) {
-            const long base = chunk_idx(G, tile, s0) * (long)(B * NL);
-            for (int i = threadIdx.x; i < run; i += 256) chunk_out[base + i] = tbuf[i];
-        } else {
-            for (int i = threadIdx.x; i < run; i += 256)
-                chunk_out[chunk_idx(G, tile, s0 + i / (B * NL)) * (long)(B * NL) + i % (B * NL)] = tbuf[i];
-        }
-    }
-}
-
-// PK: the right-hand side comes, and the result goes, in the tile's chunk order ([chunk][field][lane]: k_ilu_pack /
-// k_ilu_unpack): in the grid layout the lanes of a wave sit n0 doubles apart, so every vector load or store of the sweep
-// touches one cache line PER LANE -- 54 line transactions per instruction on C4, 9 such instructions per step in the
-// serial chain of a tile (measured: 0.065 of the sweep's 0.185 ms).  Many-wave kernels do that transposition for free.
 // (The lambdas are force-inlined: left to its heuristics the compiler outlines them in the larger instantiations, the
 // register arrays they capture by reference then live in scratch memory, and the sweep is ten times slower.)
 // BLK: grid-layout vectors moved in blocks of RF / RB steps (below); off for the short 2-D tiles, where the delayed block stores
 // only lengthen the tail
-template <int B, bool YLDS, bool PK, bool BLK>
+template <int B, bool YLDS, bool BLK>
 __global__ __launch_bounds__(64 * B) void k_ilu_solve_mw(IluGeom G, const double *__restrict__ fwd,
                                                          const double *__restrict__ bwd, const double *__restrict__ rhs,
                                                          double *__restrict__ ytmp, double *x, const double *addto, int nadd) {
@@ -654,8 +597,7 @@ __global__ __launch_bounds__(64 * B) void k_ilu_solve_mw(IluGeom G, const double
             const double2 *ch = reinterpret_cast<const double2 *>(fwd + (chunk_idx(G, tile, s) * B + r) * (long)(2 * M::PFR * NL)) + la;
 #pragma unroll
             for (int p = 0; p < M::PFR; ++p) v[k][p] = ch[(long)p * NL];
-            if (PK) rr[k] = rhs[(chunk_idx(G, tile, s) * B + r) * (long)NL + la];
-            else if (!BLK) rr[k] = rhs[(long)r * nt + (okk[k] ? c : park)];
+            if (!BLK) rr[k] = rhs[(long)r * nt + (okk[k] ? c : park)];
         };
         auto step = [&](int k, int s, double rhs_k) __attribute__((always_inline)) {
             const double *yp = yl + (size_t)(YLDS ? s : (s & 1)) * slotsz;      // y of step s-1
@@ -670,7 +612,7 @@ __global__ __launch_bounds__(64 * B) void k_ilu_solve_mw(IluGeom G, const double
             }
             // (a 0/1 factor, not a select: the compiler turns `ok ? expr : 0` into a branch around the LDS reads, and a
             // divergent branch makes it drain the prefetched loads at every step)
-            const double y = (okk[k] ? 1.0 : 0.0) * (((PK || !BLK) ? rr[k] : rhs_k) - (acc[0] + acc[1] + acc[2]));
+            const double y = (okk[k] ? 1.0 : 0.0) * ((BLK ? rhs_k : rr[k]) - (acc[0] + acc[1] + acc[2]));
             double *dst = yl + (size_t)(YLDS ? s + 1 : ((s + 1) & 1)) * slotsz + r * NL + lane;
             *(live ? dst : ldump) = y;
             if (!YLDS) *(live ? ytmp + (chunk_idx(G, tile, s) * B + r) * (long)NL + lane : gdump) = y;
@@ -678,7 +620,7 @@ __global__ __launch_bounds__(64 * B) void k_ilu_solve_mw(IluGeom G, const double
         };
         // RF steps on the values of `cur`, with the block of the following RF steps loaded into `nxt` first
         auto half = [&](double (&cur)[RF], double (&nxt)[RF], int s, auto guarded) __attribute__((always_inline)) {
-            if (BLK && !PK) blockload(nxt, s + RF);
+            if (BLK) blockload(nxt, s + RF);
 #pragma unroll
             for (int k = 0; k < RF; ++k) {
                 if (!decltype(guarded)::value || s + k < ns) {
@@ -687,7 +629,7 @@ __global__ __launch_bounds__(64 * B) void k_ilu_solve_mw(IluGeom G, const double
                 }
             }
         };
-        if (BLK && !PK) blockload(rrA, 0);
+        if (BLK) blockload(rrA, 0);
 #pragma unroll
         for (int k = 0; k < RF; ++k)
             if (k < ns) load(k, k);
@@ -726,7 +668,7 @@ __global__ __launch_bounds__(64 * B) void k_ilu_solve_mw(IluGeom G, const double
 #pragma unroll
                 for (int q = 0; q < B; ++q) yb[k][q] = ytmp[(chunk_idx(G, tile, s) * B + q) * (long)NL + la];
             }
-            if (!BLK && !PK) { cc[k] = okk[k] ? c : park; aa[k] = asrc[cc[k]]; }
+            if (!BLK) { cc[k] = okk[k] ? c : park; aa[k] = asrc[cc[k]]; }
         };
         auto step = [&](int k, int s) __attribute__((always_inline)) {
             const double *xp = xl + (size_t)((s + 1) & 1) * slotsz;             // x of step s+1
@@ -746,18 +688,14 @@ __global__ __launch_bounds__(64 * B) void k_ilu_solve_mw(IluGeom G, const double
             const double xv = (okk[k] ? 1.0 : 0.0) * (t - (acc[0] + acc[1] + acc[2]));
             double *dst = xl + (size_t)(s & 1) * slotsz + r * NL + lane;
             *(live ? dst : ldump) = xv;
-            if (PK) {
-                double *gx = x + (chunk_idx(G, tile, s) * B + r) * (long)NL + lane;
-                *(live ? gx : gdump) = xv;
-            }
-            if (!BLK && !PK) x[(long)r * nt + cc[k]] = (okk[k] ? 1.0 : 0.0) * (amask * aa[k] + xv);
+            if (!BLK) x[(long)r * nt + cc[k]] = (okk[k] ? 1.0 : 0.0) * (amask * aa[k] + xv);
             xq[k] = xv;
             TP_LDS_BARRIER();
         };
         // RB steps with the addto values of `cur`, the block of the following RB steps loaded into `nxt` first
         auto half = [&](double (&cur)[RB], double (&nxt)[RB], int s, auto guarded) __attribute__((always_inline)) {
             bool okq[RB];
-            if (BLK && !PK) blockload(nxt, s - RB);
+            if (BLK) blockload(nxt, s - RB);
 #pragma unroll
             for (int k = 0; k < RB; ++k) {
                 okq[k] = false;
@@ -767,7 +705,7 @@ __global__ __launch_bounds__(64 * B) void k_ilu_solve_mw(IluGeom G, const double
                     if (!decltype(guarded)::value || s - k - RB >= 0) load(k, s - k - RB);
                 }
             }
-            if (BLK && !PK) {
+            if (BLK) {
                 // lanes without a cell write 0.0 to an entry of x's lower halo plane (as the one-wave sweep does)
 #pragma unroll
                 for (int k = 0; k < RB; ++k)
@@ -778,7 +716,7 @@ __global__ __launch_bounds__(64 * B) void k_ilu_solve_mw(IluGeom G, const double
         // (without YLDS the forward sweep's y stores of the last steps may still be in flight: every wave re-reads values
         // written by OTHER waves of the workgroup, so drain them and make them visible first)
         if (!YLDS) { __threadfence_block(); __syncthreads(); }
-        if (BLK && !PK) blockload(aA, ns - 1);
+        if (BLK) blockload(aA, ns - 1);
 #pragma unroll
         for (int k = 0; k < RB; ++k)
             if (ns - 1 - k >= 0) load(k, ns - 1 - k);
@@ -1095,8 +1033,6 @@ static IluGeom geom_of(const tp_ctx *c) {
     G.nsteps = c->ilu.nsteps;
     G.nl = G.t1 * G.t2;
     G.ntiles = c->ilu.ntiles;
-    static const bool smajor = getenv("TP_ILU_SMAJOR") && atoi(getenv("TP_ILU_SMAJOR")) == 1;      // (measured neutral: off)
-    G.smajor = (smajor && c->ilu.levels == 0) ? 1 : 0;
     G.rs = ilu_compact(c) ? 2 * ((G.nl + ILU_ROW_ALIGN - 1) / ILU_ROW_ALIGN * ILU_ROW_ALIGN) : 128;
     return G;
 }
@@ -1145,18 +1081,6 @@ void ilu_setup(tp_ctx *c) {
         return;
     }
     if (c->b == 3) alloc_factor<3>(d, ilu_compact(c)); else alloc_factor<2>(d, ilu_compact(c));
-    // chunk-ordered right-hand side / solution (k_ilu_transpose before and after the sweep; TP_ILU_PACK=1): measured
-    // against the per-step grid-layout accesses it gained 13 % on the C5 slab and nothing on C4; the block transfers of
-    // the sweep itself (BLK) do better on both (C5 slab 1.56 -> 1.27 ms, C4 0.185 -> 0.15 ms), so it is off by default
-    const bool pk_on = getenv("TP_ILU_PACK") && atoi(getenv("TP_ILU_PACK")) == 1;
-    if (d.mw && pk_on) {
-        const size_t pkn = (size_t)d.ntiles * d.nsteps * c->b * d.t1 * d.t2;
-        d.rpk.alloc(pkn);
-        d.xpk.alloc(pkn);
-    } else {
-        d.rpk.free();
-        d.xpk.free();
-    }
 }
 
 void ilu_factor(tp_ctx *c) {
@@ -1222,30 +1146,16 @@ void ilu_solve(tp_ctx *c, const double *r, double *x, const double *addto, int n
         const size_t full = ((size_t)G.nsteps + 1 + 2) * slot + dump, ring = 4 * slot + dump;
         static const bool ylds_mw = !(getenv("TP_ILU_YLDS") && atoi(getenv("TP_ILU_YLDS")) == 0);
         const bool yl = ylds_mw && full <= 156 * 1024;
-        const bool pk_on = c->ilu.rpk.n > 0;             // (allocated by ilu_setup: never inside a stream capture)
-        const size_t tbytes = (size_t)ILU_SEG * c->b * G.nl * sizeof(double);
-#define TP_ILU_MW_LAUNCH(BB, YY, KK)                                                                                        \
+#define TP_ILU_MW_LAUNCH(BB, YY, KK)                                                                                    \
         do {                                                                                                            \
             static bool attr_set = false;                                                                               \
             if (!attr_set) {                                                                                            \
-                TP_HIP(hipFuncSetAttribute(reinterpret_cast<const void *>(&k_ilu_solve_mw<BB, YY, false, KK>),              \
-                                           hipFuncAttributeMaxDynamicSharedMemorySize, 156 * 1024));                    \
-                TP_HIP(hipFuncSetAttribute(reinterpret_cast<const void *>(&k_ilu_solve_mw<BB, YY, true, KK>),               \
+                TP_HIP(hipFuncSetAttribute(reinterpret_cast<const void *>(&k_ilu_solve_mw<BB, YY, KK>),                 \
                                            hipFuncAttributeMaxDynamicSharedMemorySize, 156 * 1024));                    \
                 attr_set = true;                                                                                        \
             }                                                                                                           \
-            if (pk_on) {                                                                                                \
-                hipLaunchKernelGGL((k_ilu_transpose<BB, true>), dim3(c->ilu.ntiles, (G.nsteps + ILU_SEG - 1) / ILU_SEG),    \
-                                   dim3(256), tbytes, c->stream, G, r, nullptr, nullptr, c->ilu.rpk.p, nullptr, 0);      \
-                hipLaunchKernelGGL((k_ilu_solve_mw<BB, YY, true, KK>), dim3(c->ilu.ntiles), dim3(64 * BB), YY ? full : ring, \
-                                   c->stream, G, c->ilu.fwd.p, c->ilu.bwd.p, c->ilu.rpk.p, c->ilu.ytmp.p, c->ilu.xpk.p, \
-                                   nullptr, 0);                                                                         \
-                hipLaunchKernelGGL((k_ilu_transpose<BB, false>), dim3(c->ilu.ntiles, (G.nsteps + ILU_SEG - 1) / ILU_SEG),   \
-                                   dim3(256), tbytes, c->stream, G, nullptr, x, c->ilu.xpk.p, nullptr, addto, nadd);     \
-            } else {                                                                                                    \
-                hipLaunchKernelGGL((k_ilu_solve_mw<BB, YY, false, KK>), dim3(c->ilu.ntiles), dim3(64 * BB), YY ? full : ring, \
-                                   c->stream, G, c->ilu.fwd.p, c->ilu.bwd.p, r, c->ilu.ytmp.p, x, addto, nadd);         \
-            }                                                                                                           \
+            hipLaunchKernelGGL((k_ilu_solve_mw<BB, YY, KK>), dim3(c->ilu.ntiles), dim3(64 * BB), YY ? full : ring,      \
+                               c->stream, G, c->ilu.fwd.p, c->ilu.bwd.p, r, c->ilu.ytmp.p, x, addto, nadd);             \
         } while (0)
         static const int blk_env = getenv("TP_ILU_BLOCK") ? atoi(getenv("TP_ILU_BLOCK")) : -1;
         const bool blk = blk_env >= 0 ? blk_env == 1 : c->g.gn2 > 1;       // 3-D tiles: whole axis-0 lines, long sweeps
