@@ -265,7 +265,8 @@ void orthogonalize(tp_ctx *c, int nf, const double *V, long vstride, int k, doub
 void field_minmax(tp_ctx *c, const double *x, double *lo, double *hi);
 void field_clamp01(tp_ctx *c, double *x);
 // stencil operators
-void spmv_block(tp_ctx *c, const double *J, const double *x, double *y);                 // y = J x
+void spmv_block(tp_ctx *c, const double *J, const double *x, double *y);
+void spmv_block_halo(tp_ctx *c, const double *J, double *x, double *y);          // exchange x's halos, y = J x; interior overlaps the exchange                 // y = J x
 void resid_block_cols(tp_ctx *c, const double *J, const double *x, const double *y, int ncols, double *r);  // r = x - J[:, :ncols] y
 void spmv_scalar(tp_ctx *c, const GridDev &g, const Stencil &A, const double *x, double *y, double alpha, const double *z);  // y = z + alpha*A x (z may be null)
 void decouple(tp_ctx *c);

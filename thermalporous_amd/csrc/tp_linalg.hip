@@ -351,13 +351,15 @@ void field_clamp01(tp_ctx *c, double *x) {
 
 // ---- block stencil mat-vec: y = J x  (MatMult) ----------------------------------------------------
 // MODE 0: y = J x ; MODE 1: r = x0 - J[:, :NC] y   (stage-1 output has zero secondary fields)
+// (first, count): the owned cells [first, first + count) -- the whole slab, or a range of planes when the boundary planes
+// wait for a halo exchange that the interior overlaps (spmv_block_halo)
 template <int B, int NS, int NC, int MODE>
 __global__ __launch_bounds__(256) void k_spmv_block(GridDev g, const double *__restrict__ J,
                                                     const double *__restrict__ x, const double *__restrict__ x0,
-                                                    double *__restrict__ y) {
+                                                    double *__restrict__ y, long first, long count) {
     const long tid = xcd_tid();
-    if (tid >= g.nown) return;
-    const long c = g.np + tid, nt = g.ntot;
+    if (tid >= count) return;
+    const long c = g.np + first + tid, nt = g.ntot;
     const long off[7] = {0, -1, 1, -(long)g.n0, (long)g.n0, -g.np, g.np};
     double acc[B];
 #pragma unroll
@@ -376,25 +378,52 @@ __global__ __launch_bounds__(256) void k_spmv_block(GridDev g, const double *__r
     for (int r = 0; r < B; ++r) y[(long)r * nt + c] = MODE ? x0[(long)r * nt + c] - acc[r] : acc[r];
 }
 
-void spmv_block(tp_ctx *c, const double *J, const double *x, double *y) {
+static void spmv_block_range(tp_ctx *c, hipStream_t st, const double *J, const double *x, double *y, long first, long count) {
     const GridDev &g = c->g;
-    const dim3 gr = xcd_grid(g.nown), bl(256);
+    const dim3 gr = xcd_grid(count), bl(256);
     const bool d3 = g.gn2 > 1;
     if (c->b == 3) {
-        if (d3) hipLaunchKernelGGL((k_spmv_block<3, 7, 3, 0>), gr, bl, 0, c->stream, g, J, x, x, y);
-        else    hipLaunchKernelGGL((k_spmv_block<3, 5, 3, 0>), gr, bl, 0, c->stream, g, J, x, x, y);
+        if (d3) hipLaunchKernelGGL((k_spmv_block<3, 7, 3, 0>), gr, bl, 0, st, g, J, x, x, y, first, count);
+        else    hipLaunchKernelGGL((k_spmv_block<3, 5, 3, 0>), gr, bl, 0, st, g, J, x, x, y, first, count);
     } else {
-        if (d3) hipLaunchKernelGGL((k_spmv_block<2, 7, 2, 0>), gr, bl, 0, c->stream, g, J, x, x, y);
-        else    hipLaunchKernelGGL((k_spmv_block<2, 5, 2, 0>), gr, bl, 0, c->stream, g, J, x, x, y);
+        if (d3) hipLaunchKernelGGL((k_spmv_block<2, 7, 2, 0>), gr, bl, 0, st, g, J, x, x, y, first, count);
+        else    hipLaunchKernelGGL((k_spmv_block<2, 5, 2, 0>), gr, bl, 0, st, g, J, x, x, y, first, count);
     }
     TP_HIP(hipGetLastError());
+}
+
+void spmv_block(tp_ctx *c, const double *J, const double *x, double *y) {
+    spmv_block_range(c, c->stream, J, x, y, 0, c->g.nown);
+}
+
+// y = J x on a slab whose halo planes of x are stale: the interior planes (which read no halo) run on a second stream while
+// the halo exchange -- RCCL send/recv, always on the main stream: one communicator, one stream -- is in flight; the two
+// boundary planes follow the exchange on the main stream, which then joins the interior (SURVEY.md 8e "overlap with
+// interior rows").  Per-cell arithmetic unchanged: bitwise the result of exchange-then-SpMV.
+void spmv_block_halo(tp_ctx *c, const double *J, double *x, double *y) {
+    const GridDev &g = c->g;
+    static const bool overlap = !(getenv("TP_HALO_OVERLAP") && atoi(getenv("TP_HALO_OVERLAP")) == 0);
+    if (!c->dist) { spmv_block(c, J, x, y); return; }
+    if (!overlap || g.n2 < 3) {
+        halo_exchange(c, g, x, c->b, g.ntot);
+        spmv_block(c, J, x, y);
+        return;
+    }
+    TP_HIP(hipEventRecord(c->ev_fork, c->stream));                 // x is final on the main stream
+    TP_HIP(hipStreamWaitEvent(c->aux[0], c->ev_fork, 0));
+    spmv_block_range(c, c->aux[0], J, x, y, g.np, g.np * (g.n2 - 2));      // planes 1 .. n2-2
+    TP_HIP(hipEventRecord(c->ev_join[0], c->aux[0]));
+    halo_exchange(c, g, x, c->b, g.ntot);
+    spmv_block_range(c, c->stream, J, x, y, 0, g.np);                      // plane 0 (reads the lower halo)
+    spmv_block_range(c, c->stream, J, x, y, g.np * (g.n2 - 1), g.np);      // plane n2-1 (reads the upper halo)
+    TP_HIP(hipStreamWaitEvent(c->stream, c->ev_join[0], 0));
 }
 
 void resid_block_cols(tp_ctx *c, const double *J, const double *x, const double *y, int ncols, double *r) {
     const GridDev &g = c->g;
     const dim3 gr = xcd_grid(g.nown), bl(256);
     const bool d3 = g.gn2 > 1;
-#define RL(B, NS, NC) hipLaunchKernelGGL((k_spmv_block<B, NS, NC, 1>), gr, bl, 0, c->stream, g, J, y, x, r)
+#define RL(B, NS, NC) hipLaunchKernelGGL((k_spmv_block<B, NS, NC, 1>), gr, bl, 0, c->stream, g, J, y, x, r, 0L, g.nown)
     if (c->b == 3) {
         if (ncols == 1) { if (d3) RL(3, 7, 1); else RL(3, 5, 1); }
         else if (ncols == 2) { if (d3) RL(3, 7, 2); else RL(3, 5, 2); }

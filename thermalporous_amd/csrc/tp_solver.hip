@@ -418,8 +418,7 @@ int fgmres(tp_ctx *c, const double *bvec, double *x, int *its_out, double *rnorm
             ensure_basis(j + 2);
             double *vj = c->V.p + (long)j * nv, *zj = c->Z.p + (long)j * nv, *w = c->V.p + (long)(j + 1) * nv;
             pc_apply(c, vj, zj);                                            // z_j = M^-1 v_j
-            if (c->dist) halo_exchange(c, g, zj, B, g.ntot);
-            spmv_block(c, c->J.p, zj, w);                                   // w = J z_j
+            spmv_block_halo(c, c->J.p, zj, w);                              // w = J z_j (multi-GPU: exchange of z_j's halos overlapped)
             orthogonalize(c, B, c->V.p, nv, j + 1, w, hcol.data());         // h = V^T w ; w -= V h ; ||w||^2
             const double hn = std::sqrt(hcol[j + 1]);
             for (int i = 0; i <= j; ++i) H[(size_t)i * m + j] = hcol[i];
