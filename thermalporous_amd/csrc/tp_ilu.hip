@@ -542,6 +542,9 @@ __global__ __launch_bounds__(64) void k_ilu_solve(IluGeom G, const double *__res
         __builtin_amdgcn_s_barrier();                                           \
         __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "workgroup", "local");         \
     } while (0)
+// two doubles at 8-byte alignment: one 16-byte access per lane where the hardware allows unaligned vector accesses
+typedef double double2_u __attribute__((ext_vector_type(2), aligned(8)));
+
 template <int B> struct IluMwLayout {
     static constexpr int PFR = (3 * B + 1) / 2;      // double2 pairs per forward row: B_a[r][q], a = 0..2 (+ padding half)
     static constexpr int PBR = (4 * B + 1) / 2;      // pairs per backward row: C_a[r][q], a = 0..2, then D~^-1[r][q]
@@ -587,10 +590,14 @@ __global__ __launch_bounds__(64 * B) void k_ilu_solve_mw(IluGeom G, const double
         // fetched from L2 sixteen times (the CU's L1 does not hold the ~270 lines the three waves touch per step until the
         // next step).  Loaded RF values at a time, back to back, it is fetched twice: blocks of RF steps, double buffered.
         const long cb = G.g.np + (long)ti.base0 + (long)G.g.n0 * (ti.base1 + ti.j) + G.g.np * (ti.base2 + ti.k) - (ti.j + ti.k);
-        auto blockload = [&](double (&dst)[RF], int s) __attribute__((always_inline)) {      // values of steps s .. s+RF-1 (addresses clamped: unused ones are masked)
-            const double *col = rhs + (long)r * nt;
+        auto blockload = [&](double (&dst)[RF], int s) __attribute__((always_inline)) {      // values of steps s .. s+RF-1 (block clamped into the vector: unused values are masked)
+            const double2_u *col = reinterpret_cast<const double2_u *>(rhs + (long)r * nt + min(max(cb + s, 0L), nt - RF));
 #pragma unroll
-            for (int q = 0; q < RF; ++q) dst[q] = col[min(max(cb + s + q, 0L), nt - 1)];
+            for (int q = 0; q < RF / 2; ++q) {
+                const double2_u t = col[q];
+                dst[2 * q] = t.x;
+                dst[2 * q + 1] = t.y;
+            }
         };
         auto load = [&](int k, int s) __attribute__((always_inline)) {
             okk[k] = tile_cell(G, ti, s, l0, c) && live;
@@ -656,8 +663,13 @@ __global__ __launch_bounds__(64 * B) void k_ilu_solve_mw(IluGeom G, const double
         // `addto` in blocks of RB steps, like the right-hand side of the forward sweep; the RB results of a block are stored
         // back to back at its end (x may alias addto: a block's loads are all issued before the stores of the block before)
         auto blockload = [&](double (&dst)[RB], int s) __attribute__((always_inline)) {      // values of steps s, s-1, .., s-RB+1
+            const double2_u *col = reinterpret_cast<const double2_u *>(asrc + min(max(cb + s - (RB - 1), 0L), nt - RB));
 #pragma unroll
-            for (int q = 0; q < RB; ++q) dst[q] = asrc[min(max(cb + s - q, 0L), nt - 1)];
+            for (int q = 0; q < RB / 2; ++q) {
+                const double2_u t = col[q];                // cells of steps s-(RB-1)+2q and s-(RB-1)+2q+1
+                dst[RB - 1 - 2 * q] = t.x;
+                dst[RB - 2 - 2 * q] = t.y;
+            }
         };
         auto load = [&](int k, int s) __attribute__((always_inline)) {
             okk[k] = tile_cell(G, ti, s, l0, c) && live;
@@ -706,7 +718,8 @@ __global__ __launch_bounds__(64 * B) void k_ilu_solve_mw(IluGeom G, const double
                 }
             }
             if (BLK) {
-                // lanes without a cell write 0.0 to an entry of x's lower halo plane (as the one-wave sweep does)
+                // lanes without a cell write 0.0 to an entry of x's lower halo plane (as the one-wave sweep does); (16-byte stores
+                // of neighbouring results, with single stores at the column ends, were measured: no gain)
 #pragma unroll
                 for (int k = 0; k < RB; ++k)
                     if (!decltype(guarded)::value || s - k >= 0)
