@@ -16,8 +16,7 @@ Nxyz = tuple(int(v) for v in sys.argv[1:4])
 nranks = int(sys.argv[4])
 nsteps = int(sys.argv[5]) if len(sys.argv) > 5 else 2
 extra = eval(sys.argv[6]) if len(sys.argv) > 6 else {}
-refine = int(os.environ.get("REFINE", "1"))
-m = bench.make_model("c4", Nxyz=Nxyz, refine=refine)
+m = bench.make_model("c4", Nxyz=Nxyz)
 spec, opts = m.spec, dict(m.engine_opts, **extra)
 m.start()
 m.u.flush() if hasattr(m.u, "flush") else None
