@@ -11,7 +11,7 @@ case "$1" in
 a)
   python -m pytest tests -m gpu -q -x -v > $OUT/pytest_gpu.log 2>&1 || { tail -30 $OUT/pytest_gpu.log; exit 1; }
   tail -3 $OUT/pytest_gpu.log
-  python bench.py --steps 8 --warmup 2 > $OUT/bench_default.json 2> $OUT/bench_default.err     # (a short window, with its failed solve)
+  python bench.py --steps 8 --warmup 2 > $OUT/bench_short_window.json 2> $OUT/bench_short_window.err     # (a short window, with its failed solve)
   python bench.py --steps 20 --warmup 5 > $OUT/bench_driver.json 2> $OUT/bench_driver.err
   ;;
 b)
