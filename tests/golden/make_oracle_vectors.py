@@ -7,7 +7,7 @@ What the fixture is for: (a) the oracle is pinned against drift (tests/test_gold
 
 Per case: the perturbed state u, the old state u0, dt -> residual R, Jacobian J (7,b,b,...), [S~], and one
 Newton solve from u0 (converged state, Newton / Krylov iteration counts).
-usage: python tests/golden/make_oracle_vectors.py
+usage: python tests/golden/make_oracle_vectors.py [r1|r2|all]     (default r2)
 """
 import os
 import sys
@@ -29,9 +29,20 @@ CASES = {
     "c4_1ph_3d_fscd": (cases.c4_spe10_3d, dict(Nx=6, Ny=7, Nz=5, nphase=1), dict(pc="fieldsplit_cd", ksp_rtol=1e-8, amg_dom_tau=0.0), 864.0),
 }
 
+# round 2 additions, in a file of their own (oracle_vectors_r2.npz) so that the round-1 fixture stays byte-identical:
+# block-ILU(1), selfp, the system AMG of pc_cptramg, and the engines' current defaults (balanced tiles, amg_dom_tau 0.25:
+# the S~ hierarchy of the last case ends with relaxation only)
+CASES_R2 = {
+    "c4_2ph_3d_ilu1": (cases.c4_spe10_3d, dict(Nx=6, Ny=7, Nz=5, nphase=2), dict(pc="cpr", ilu_levels=1, ksp_rtol=1e-8, snes_max_it=25), 86.4),
+    "c2_1ph_2d_selfp": (cases.c3_spe10_2d, dict(Nx=10, Ny=12, nphase=1), dict(pc="fieldsplit_cd", schur_selfp=True, ksp_rtol=1e-8), 8640.0),
+    "c4_2ph_3d_cptramg_QI": (cases.c4_spe10_3d, dict(Nx=6, Ny=7, Nz=5, nphase=2), dict(pc="cptramg", decoup="QI", ksp_rtol=1e-8, snes_max_it=25), 86.4),
+    "c4_2ph_3d_defaults": (cases.c4_spe10_3d, dict(Nx=6, Ny=9, Nz=7, nphase=2), dict(pc="cptr", ksp_rtol=1e-8, snes_max_it=25), 86.4),
+}
+ALL_CASES = {**CASES, **CASES_R2}
+
 
 def compute(name):
-    builder, kw, opts, dt = CASES[name]
+    builder, kw, opts, dt = ALL_CASES[name]
     spec, u0, *_ = builder(**kw)
     o = OracleEngine(spec, opts)
     u = cases.perturbed_state(spec, seed=3)
@@ -53,9 +64,13 @@ def compute(name):
 
 
 if __name__ == "__main__":
-    blob = {}
-    for name in CASES:
-        for k, v in compute(name).items():
-            blob[name + "/" + k] = v
-    np.savez_compressed(os.path.join(HERE, "oracle_vectors.npz"), **blob)
-    print("wrote", len(blob), "arrays,", os.path.getsize(os.path.join(HERE, "oracle_vectors.npz")), "bytes")
+    which = sys.argv[1] if len(sys.argv) > 1 else "r2"          # "r1": regenerate the round-1 file as well
+    for tag, table, fname in (("r1", CASES, "oracle_vectors.npz"), ("r2", CASES_R2, "oracle_vectors_r2.npz")):
+        if tag != which and which != "all":
+            continue
+        blob = {}
+        for name in table:
+            for k, v in compute(name).items():
+                blob[name + "/" + k] = v
+        np.savez_compressed(os.path.join(HERE, fname), **blob)
+        print("wrote", fname, len(blob), "arrays,", os.path.getsize(os.path.join(HERE, fname)), "bytes")

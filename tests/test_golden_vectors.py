@@ -1,4 +1,4 @@
-"""Committed golden vectors (tests/golden/oracle_vectors.npz, made by tests/golden/make_oracle_vectors.py from the
+"""Committed golden vectors (tests/golden/oracle_vectors.npz and oracle_vectors_r2.npz, made by tests/golden/make_oracle_vectors.py from the
 CPU oracle -- the reference itself cannot run here, parity with it stays unpinned).  CPU: the oracle still
 reproduces them.  GPU: the HIP path, through the C ABI, reproduces them."""
 import importlib.util
@@ -12,14 +12,15 @@ _spec = importlib.util.spec_from_file_location("make_oracle_vectors", os.path.jo
 gen = importlib.util.module_from_spec(_spec)
 _spec.loader.exec_module(gen)
 
-GOLD = np.load(os.path.join(HERE, "golden", "oracle_vectors.npz"), allow_pickle=False)
+_files = [np.load(os.path.join(HERE, "golden", f), allow_pickle=False) for f in ("oracle_vectors.npz", "oracle_vectors_r2.npz")]
+GOLD = {k: f[k] for f in _files for k in f.files}          # (round-2 cases live in a file of their own)
 
 
 def relmax(a, b):
     return np.abs(a - b).max()/max(np.abs(b).max(), 1e-300)
 
 
-@pytest.mark.parametrize("name", sorted(gen.CASES))
+@pytest.mark.parametrize("name", sorted(gen.ALL_CASES))
 def test_oracle_reproduces_golden_vectors(name):
     out = gen.compute(name)
     for k, v in out.items():
@@ -31,12 +32,12 @@ def test_oracle_reproduces_golden_vectors(name):
 
 
 @pytest.mark.gpu
-@pytest.mark.parametrize("name", sorted(gen.CASES))
+@pytest.mark.parametrize("name", sorted(gen.ALL_CASES))
 def test_hip_path_reproduces_golden_vectors(name):
     from thermalporous_amd.engine import HipEngine
-    builder, kw, opts, dt = gen.CASES[name]
+    builder, kw, opts, dt = gen.ALL_CASES[name]
     spec, u0, *_ = builder(**kw)
-    g = {k.split("/", 1)[1]: GOLD[k] for k in GOLD.files if k.startswith(name + "/")}
+    g = {k.split("/", 1)[1]: v for k, v in GOLD.items() if k.startswith(name + "/")}
     assert np.array_equal(g["u0"], u0)                                   # the seeded inputs are the fixture's
     h = HipEngine(spec, opts)
     h.set_old(g["u0"])
