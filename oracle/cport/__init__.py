@@ -46,7 +46,7 @@ def build():
 def load():
     global _LIB
     if _LIB is None:
-        if not os.path.exists(_LIBPATH):
+        if not os.path.exists(_LIBPATH) or os.path.getmtime(_LIBPATH) < os.path.getmtime(os.path.join(_DIR, "tp_cport.cpp")):
             build()
         # pin the OpenMP threads (read by libgomp when it is first loaded): unbound threads migrate between cores and a
         # parallel region then costs tens of milliseconds on shared hosts -- measured 59 ms vs 5 ms for a 1M-cell loop
@@ -58,6 +58,14 @@ def load():
         lib.cp_amg_levels.restype = C.c_int
         lib.cp_ntiles.restype = C.c_int
         lib.cp_amg_trunc.restype = C.c_int
+        # a stale library (older checkout, other struct layout) must not be compared against silently
+        try:
+            sizes = (lib.cp_sizeof_opts(), lib.cp_sizeof_info())
+        except AttributeError:
+            sizes = None
+        if sizes != (C.sizeof(_Opts), C.sizeof(_Info)):
+            raise RuntimeError("oracle/cport/libtp_cport.so does not match this checkout's ABI (%r vs %r): run `make -C "
+                               "oracle/cport clean all`" % (sizes, (C.sizeof(_Opts), C.sizeof(_Info))))
         _LIB = lib
     return _LIB
 

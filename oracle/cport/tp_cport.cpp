@@ -1586,6 +1586,9 @@ void *cp_create(int nphase, const int *n, const double *h, int gaxis, const doub
 void cp_destroy(void *c) { delete (Ctx *)c; }
 void cp_set_threads(int n) { omp_set_num_threads(n > 0 ? n : 1); }
 int cp_max_threads(void) { return omp_get_max_threads(); }
+// ABI guard: the Python loader compares these with ctypes.sizeof of its mirrors (a stale .so from an older checkout fails loudly)
+int cp_sizeof_opts(void) { return (int)sizeof(Opts); }
+int cp_sizeof_info(void) { return (int)sizeof(Info); }
 
 void cp_set_state(void *c, const double *u) { Ctx *C = (Ctx *)c; std::copy(u, u + C->u.size(), C->u.begin()); }
 void cp_get_state(void *c, double *u) { Ctx *C = (Ctx *)c; std::copy(C->u.begin(), C->u.end(), u); }

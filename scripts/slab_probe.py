@@ -12,6 +12,10 @@ import numpy as np
 import bench
 from thermalporous_amd import engine as E
 
+if len(sys.argv) in (2, 3, 4) or (len(sys.argv) > 1 and sys.argv[1] in ("-h", "--help")):
+    raise SystemExit(__doc__)
+if len(sys.argv) == 1:                       # no arguments: C4's own geometry on 4 in-process slabs
+    sys.argv += ["60", "220", "85", "4"]
 Nxyz = tuple(int(v) for v in sys.argv[1:4])
 nranks = int(sys.argv[4])
 nsteps = int(sys.argv[5]) if len(sys.argv) > 5 else 2

@@ -78,6 +78,10 @@ def test_c2_c3_true_size_60x220(nphase, opts, dts):
         # the tiny first steps are almost linear: the second Newton iterate sits AT the convergence thresholds
         # (||F|| <= 1e-8 ||F0|| vs ||dx|| < 1e-8 ||x||), so which test fires first, and with it the last iteration,
         # may differ by rounding; both must converge to the same state within the solver tolerance
+        # TOLERANCES here (Newton +-1, states 1e-7 instead of the file-wide "equal" / 1e-8): a run that stops one Newton
+        # iteration earlier holds a state whose error is the LAST update, bounded by the stol/rtol tests at 1e-8 relative
+        # to ||x|| per field but up to ~1e-7 in the 2-norm of a single field; cases that take the same number of
+        # iterations agree to 1e-9 (test_c4_true_size_vs_cport checks that bar)
         assert ro["reason"] > 0 and rh["reason"] > 0, (ro, rh)
         assert abs(rh["nits"] - ro["nits"]) <= 1
         assert abs(rh["lits"] - ro["lits"]) <= max(2, 0.15*ro["lits"])

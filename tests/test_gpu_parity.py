@@ -349,7 +349,10 @@ def test_dominance_truncated_hierarchy(grid, dt, expect):
     h.amg_vcycle(1, "x", 1, "y", 1)
     assert rel2(h.vec_get("y")[1], o.pc.amg_T.vcycle(x[1])) < 1e-10
     h.pc_apply("x", "y")
-    assert rel2(h.vec_get("y"), o.pc.apply(x)) < (1e-9 if dt > 1e5 else 1e-10)      # (dt = 46 days: badly conditioned)
+    # TOLERANCE: 1e-10 is the bar of every PC application in this file; the one dt = 46-day case gets 1e-9 because its
+    # stage-1 operators have condition number ~1e6 (accumulation term ~1/dt gone, pure elliptic pressure): the measured
+    # GPU-vs-oracle difference there is 1.9e-10 = eps * cond * O(1), i.e. summation order, not an algorithmic difference
+    assert rel2(h.vec_get("y"), o.pc.apply(x)) < (1e-9 if dt > 1e5 else 1e-10)
     if dt < 1e5:                  # (at dt = 46 days from a 5 % perturbed state FGMRES(200) stalls in every engine)
         import oracle.linalg as la
         F = o.residual()

@@ -226,3 +226,61 @@ def test_rccl_calls_on_a_one_rank_communicator(gather):
     assert res[0][2] == 0 and (res[1][2] > 0) == (gather == 0)
     for f in range(3):
         assert rel2(res[1][1][f], res[0][1][f]) < 1e-9
+
+
+def _pc_sequence_on_slabs(spec, u0, u, dt, xs, nranks, seq):
+    """On every slab of an in-process group: for each options dict of `seq` in turn, set_options -> jacobian ->
+    pc_setup -> pc_apply(xs).  Returns the global results of every stage of the sequence."""
+    from thermalporous_amd import engine as E
+    lib = E.load_library()
+    group = C.c_void_p()
+    assert lib.tp_local_group_create(nranks, C.byref(group)) == 0
+    out = [None]*nranks
+    err = []
+
+    def worker(rank):
+        try:
+            h = E.HipEngine(spec, seq[0], rank=rank, nranks=nranks, local_group=group)
+            h.set_old(u0)
+            h.set_dt(dt)
+            h.set_state(u)
+            res = []
+            for k, o in enumerate(seq):
+                if k:
+                    h.set_options(**o)
+                h.jacobian()
+                h.pc_setup()
+                h.vec_set("x", xs)
+                h.pc_apply("x", "y")
+                res.append(h.vec_get("y"))
+            out[rank] = res
+            h.close()
+        except Exception as e:      # noqa: BLE001
+            err.append((rank, repr(e)))
+    ts = [threading.Thread(target=worker, args=(r,)) for r in range(nranks)]
+    for t in ts:
+        t.start()
+    for t in ts:
+        t.join(timeout=300)
+    assert not any(t.is_alive() for t in ts), "slab worker hung"
+    lib.tp_local_group_destroy(group)
+    assert not err, err
+    return [np.concatenate([o[k] for o in out], axis=-3) for k in range(len(seq))]
+
+
+@pytest.mark.parametrize("seq_name", ["cptr_cptramg_cptr", "cpr_cptr"])
+def test_switching_pc_kinds_on_a_live_slab_group(seq_name):
+    """tp_set_options on a live multi-slab context: the global-grid scratch buffers (gvec, gA00, gA01, gA10, gSm,
+    gAt) are each sized from their own needs, so cptr -> cptramg -> cptr does not leave gvec with 4 planes where stage 1
+    writes 6, and cpr -> cptr does not leave gA01/gA10/gSm unallocated.  Every stage must equal a FRESH context's result."""
+    spec, u0, *_ = cases.c4_spe10_3d(Nx=8, Ny=21, Nz=7, nphase=2)
+    u = cases.perturbed_state(spec, seed=5, amp=0.2)
+    xs = np.random.default_rng(11).standard_normal(u.shape)
+    base = dict(ksp_rtol=1e-8, amg_gather_cells=2000000)          # replicated hierarchies: the global-grid scratch is in use
+    seqs = {"cptr_cptramg_cptr": [dict(base, pc="cptr"), dict(base, pc="cptramg", decoup="QI"), dict(base, pc="cptr", decoup="No")],
+            "cpr_cptr": [dict(base, pc="cpr", decoup="QI"), dict(base, pc="cptr", decoup="No")]}
+    seq = seqs[seq_name]
+    got = _pc_sequence_on_slabs(spec, u0, u, 3000.0, xs, 2, seq)
+    for k, o in enumerate(seq):
+        fresh = _pc_sequence_on_slabs(spec, u0, u, 3000.0, xs, 2, [o])[0]
+        assert rel2(got[k], fresh) < 1e-12, (seq_name, k)

@@ -1129,12 +1129,10 @@ template <int BB, bool DD, bool CC>
 static void ilu_solve_launch(tp_ctx *c, const IluGeom &G, bool ylds, size_t ybytes, const double *r, double *x,
                              const double *addto, int nadd) {
     if (ylds) {
-        static bool attr_set = false;        // (one flag per instantiation)
-        if (!attr_set) {
-            TP_HIP(hipFuncSetAttribute(reinterpret_cast<const void *>(&k_ilu_solve<BB, DD, true, CC>),
-                                       hipFuncAttributeMaxDynamicSharedMemorySize, 152 * 1024));
-            attr_set = true;
-        }
+        // set before every launch: the attribute is per device, and a process-wide "already set" flag would be wrong for a
+        // second device and racy between slab threads (the call is a host-side table update, legal inside a capture)
+        TP_HIP(hipFuncSetAttribute(reinterpret_cast<const void *>(&k_ilu_solve<BB, DD, true, CC>),
+                                   hipFuncAttributeMaxDynamicSharedMemorySize, 152 * 1024));
         hipLaunchKernelGGL((k_ilu_solve<BB, DD, true, CC>), dim3(c->ilu.ntiles), dim3(64), ybytes, c->stream, G, c->ilu.fwd.p,
                            c->ilu.bwd.p, r, c->ilu.ytmp.p, x, addto, nadd);
     } else {
@@ -1161,17 +1159,15 @@ void ilu_solve(tp_ctx *c, const double *r, double *x, const double *addto, int n
         const bool yl = ylds_mw && full <= 156 * 1024;
 #define TP_ILU_MW_LAUNCH(BB, YY, KK)                                                                                    \
         do {                                                                                                            \
-            static bool attr_set = false;                                                                               \
-            if (!attr_set) {                                                                                            \
-                TP_HIP(hipFuncSetAttribute(reinterpret_cast<const void *>(&k_ilu_solve_mw<BB, YY, KK>),                 \
-                                           hipFuncAttributeMaxDynamicSharedMemorySize, 156 * 1024));                    \
-                attr_set = true;                                                                                        \
-            }                                                                                                           \
+            TP_HIP(hipFuncSetAttribute(reinterpret_cast<const void *>(&k_ilu_solve_mw<BB, YY, KK>),                     \
+                                       hipFuncAttributeMaxDynamicSharedMemorySize, 156 * 1024));   /* per device: every launch */ \
             hipLaunchKernelGGL((k_ilu_solve_mw<BB, YY, KK>), dim3(c->ilu.ntiles), dim3(64 * BB), YY ? full : ring,      \
                                c->stream, G, c->ilu.fwd.p, c->ilu.bwd.p, r, c->ilu.ytmp.p, x, addto, nadd);             \
         } while (0)
         static const int blk_env = getenv("TP_ILU_BLOCK") ? atoi(getenv("TP_ILU_BLOCK")) : -1;
-        const bool blk = blk_env >= 0 ? blk_env == 1 : c->g.gn2 > 1;       // 3-D tiles: whole axis-0 lines, long sweeps
+        // 3-D tiles: whole axis-0 lines, long sweeps.  The block loads clamp their start into the vector; that is harmless only
+        // while every cell of a clamped block is a halo-plane cell, i.e. a plane holds at least one block (RF = 8 values)
+        const bool blk = (blk_env >= 0 ? blk_env == 1 : c->g.gn2 > 1) && c->g.np >= 8;
         if (c->b == 3) {
             if (yl) { if (blk) TP_ILU_MW_LAUNCH(3, true, true); else TP_ILU_MW_LAUNCH(3, true, false); }
             else    { if (blk) TP_ILU_MW_LAUNCH(3, false, true); else TP_ILU_MW_LAUNCH(3, false, false); }

@@ -31,6 +31,13 @@ void ensure_work(tp_ctx *c) {
     if (grew) c->graph_epoch++;          // captured pc_apply graphs hold the old addresses
 }
 
+// multi-GPU scratch on the gathered global grid: grown on demand, never shrunk; captured graphs hold the old address
+static void ensure_global(tp_ctx *c, DBuf<double> &b, size_t n) {
+    if (b.n >= n) return;
+    b.alloc(n);
+    c->graph_epoch++;
+}
+
 // mean interior-face transmissibility per axis over the GLOBAL grid (sum/count all-reduced over slabs)
 static void face_strengths(tp_ctx *c, double st[3]) {
     const long nt = c->g.ntot;
@@ -90,7 +97,8 @@ static void pc_setup_sysamg(tp_ctx *c) {
     if (c->dist) {
         // the hierarchy lives on the gathered global grid, replicated on every rank (as small scalar hierarchies do)
         const size_t ng = (size_t)c->gfull.ntot;
-        if (c->gAt.n < 28 * ng) { c->gAt.alloc(28 * ng); c->gvec.alloc(4 * ng); }
+        ensure_global(c, c->gAt, 28 * ng);
+        ensure_global(c, c->gvec, 6 * ng);      // (sized for every pc kind: switching kinds never shrinks it)
         for (int s = 0; s < 7; ++s)
             for (int q = 0; q < 2; ++q)       // the two column planes of a block row are nt apart on both sides
                 gather_slabs(c, A0.at(s, q, 0), A0.cs, c->gAt.p + ((size_t)(s * 2 + q) * 2) * ng, (long)ng, 2);
@@ -162,11 +170,11 @@ void pc_setup(tp_ctx *c) {
     if (cptr && !selfp) TP_REQUIRE(Sl.base, "pc_cptr needs the S~ operator (assemble with want_schur)");
     if (c->dist && c->amg_p->dist_levels == 0) {
         const size_t ng = (size_t)c->gfull.ntot;
-        if (c->gA00.n < 7 * ng) {
-            c->gA00.alloc(7 * ng);
-            if (cptr) { c->gA01.alloc(7 * ng); c->gA10.alloc(7 * ng); c->gSm.alloc(7 * ng); }
-            c->gvec.alloc(6 * ng);
-        }
+        // every buffer is tested on its own size (an options switch cpr -> cptr, or cptr -> cptramg -> cptr, on a live
+        // context must not find gvec shrunk or gA01/gA10/gSm missing because some OTHER buffer was already large enough)
+        ensure_global(c, c->gA00, 7 * ng);
+        if (cptr) { ensure_global(c, c->gA01, 7 * ng); ensure_global(c, c->gA10, 7 * ng); ensure_global(c, c->gSm, 7 * ng); }
+        ensure_global(c, c->gvec, 6 * ng);
         gather_slabs(c, c->opA00.base, c->opA00.slot_stride, c->gA00.p, (long)ng, 7);
         Stencil G;
         G.slot_stride = (long)ng;
