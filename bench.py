@@ -3,7 +3,7 @@
 two-phase 3-D SPE10-like 60x220x85 box, wells + heaters, pc_cptr (CPTR: fieldsplit-Schur stage 1 with
 AMG V-cycles on App and S~, block-Jacobi block-ILU(0) stage 2) inside FGMRES inside Newton.
 
-    python bench.py --gpus N --steps K --warmup W [--config c1|c2|c3|c4|c5slab]
+    python bench.py --gpus N --steps K --warmup W [--config c1|c2|c3|c4|c5|c5slab]
     python -m torch.distributed.run --nnodes=1 --nproc-per-node N ... bench.py --gpus N ...
 
 A "step" is one time step of the reference's time loop = one ``solver.solve()`` (one Newton solve with
@@ -49,6 +49,9 @@ CONFIGS = {
     "c2": ("BASELINE config 2: single-phase 2D SPE10-like 60x220 layer, Peaceman wells, pc_cpr, maxdt 1 day", (60, 220, 1)),
     "c3": ("BASELINE config 3: two-phase 2D SPE10-like 60x220 layer, Peaceman wells, pc_cptr, maxdt 1 day", (60, 220, 1)),
     "c4": ("BASELINE config 4: two-phase 3D SPE10-like 60x220x85, wells+heaters, pc_cptr, maxdt 0.1 day", (60, 220, 85)),
+    "c5": ("BASELINE config 5: two-phase 3D 240x880x340 (60x220x85 field upsampled x4, dead cells drawn at the fine "
+           "resolution), 21+21 constant-rate 'large' wells (1e-7 m^3/s), pc_cptr, maxdt 0.1 day -- the HBM-fill case for "
+           "--gpus 8 (71.8 M cells: does not fit one GPU)", (240, 880, 340)),
     "c5slab": ("BASELINE config 5, ONE of its 8 slabs: two-phase 3D 240x110x340 (60x220x85 field upsampled x4), "
                "21+21 constant-rate 'large' wells (1e-7 m^3/s), pc_cptr, maxdt 0.1 day", (240, 110, 340)),
 }
@@ -97,7 +100,7 @@ def build_case(name, Nxyz=None):
         prod = [[140.0/365.76*L, 210.0/670.56*Ly, 0.2*Lz]]
         inj = [[265.0/365.76*L, 260.0/670.56*Ly, 0.8*Lz]]
         case = WellHeaterCase(params, geo, prod_points=prod, inj_points=inj)
-    elif name == "c5slab":
+    elif name in ("c5", "c5slab"):
         geo = SPE10Model3D(Nx, Ny, Nz, params, refine=4)      # cells 1/4 of the SPE10 size in every direction
         # 21 + 21 wells on the 'large' pattern (wellcase.py:58-64) driven as the reference's own 3-D runs drive them:
         # constant rate 1e-7 m^3/s (tests_twophase/test3D_homo_wells.py:11,90).  Peaceman wells at config 4's 2e-4 m^3/s
@@ -224,6 +227,9 @@ def main():
         raise SystemExit("bench.py needs an MI355X: the hot path has no CPU fallback")
 
     Nxyz = tuple(args.grid) if args.grid else None
+    if args.config == "c5" and Nxyz is None and world < 4:
+        raise SystemExit("--config c5 is the 240x880x340 box (71.8 M cells, ~35 GB of HBM per 9 M-cell slab): launch it on 8 "
+                         "GPUs (4 at least); --config c5slab runs one of its eight slabs on one GPU")
     model = make_model(args.config, Nxyz=Nxyz)
     eng = model.engine
     model.start()

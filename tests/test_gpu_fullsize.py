@@ -307,3 +307,109 @@ def test_c5_shaped_two_slabs_in_process():
         assert a["reason"] > 0 and b["reason"] == a["reason"] and b["nits"] == a["nits"]
         assert abs(b["lits"] - a["lits"]) <= max(2, 0.1*a["lits"])       # ILU tiles restart at the slab boundary
     assert rel2(u2[0], u1[0]) < 1e-8 and rel2(u2[1], u1[1]) < 1e-8 and np.abs(u2[2] - u1[2]).max() < 1e-8
+
+
+def test_c5_full_box_eight_slabs_in_process():
+    """BASELINE config 5 AS SPECIFIED: the whole 240x880x340 box (71.8 M cells, 215 M unknowns) cut into 8 slabs of 110
+    planes, all eight driven through the library's in-process slab group on ONE 288 GB GPU -- the call sequence and buffer
+    arithmetic of the 8-GPU RCCL run (halo exchanges, 8-way distributed top AMG levels, the gathered replicated tail,
+    batched all-reduces) at the size `bench.py --config c5 --gpus 8` runs.  Size-independent properties: the pure face
+    fluxes cancel over the WHOLE box (across the seven slab interfaces), the preconditioner is linear, the FGMRES
+    solution has a true residual below the tolerance, the first time step converges with identical counts on every
+    slab.  Memory: ~21 GB per slab without the Krylov basis; ksp_restart = 10 keeps the eight bases at 4.8 GB each
+    (the default restart of 200 grows the basis on demand and is what an 8-GPU run uses: one slab per 288 GB)."""
+    import ctypes as C
+    import threading
+    import bench
+    from thermalporous_amd import engine as E
+    from thermalporous_amd.problem import build_spec
+    params, geo, case, cls, kw = bench.build_case("c5")
+    spec = build_spec(geo, case, params, 2)
+    assert sorted(spec["n"]) == [240, 340, 880] and spec["n"][2] == 880
+    del geo, case
+    u0 = cases.uniform_state(spec, params.p_ref, params.T_prod, params.S_o)
+    u = cases.perturbed_state(spec, seed=1, amp=0.05)
+    rng = np.random.default_rng(0)
+    x, y = rng.standard_normal(u.shape), rng.standard_normal(u.shape)
+    z = 2.0*x - 3.0*y
+    nranks = 8
+    lib = E.load_library()
+    group = C.c_void_p()
+    assert lib.tp_local_group_create(nranks, C.byref(group)) == 0
+    opts = dict(pc="cptr", ksp_rtol=1e-8, snes_max_it=25, ksp_restart=10, ksp_max_it=400)
+    out, err = [None]*nranks, []
+
+    def worker(rank):
+        try:
+            nosrc = dict(spec)
+            nosrc["sources"] = None
+            h = E.HipEngine(nosrc, opts, rank=rank, nranks=nranks, local_group=group)
+            res = {}
+            h.set_old(u)
+            h.set_state(u)
+            h.set_dt(3.0)
+            R = h.residual()                                  # u == u_old: pure face fluxes
+            res["flux_sum"] = [float(R[f].sum()) for f in range(3)]
+            res["flux_abs"] = [float(np.abs(R[f]).sum()) for f in range(3)]
+            del R
+            h.set_old(u0)
+            h.set_state(u)
+            h._ck(h.lib.tp_jacobian(h.ctx))
+            h.pc_setup()
+            res["layout"] = h.amg_layout(0)
+            for name, v in (("mx", x), ("my", y), ("mz", z)):
+                h.vec_set("x", v)
+                h.pc_apply("x", name)
+            mx, my, mz = h.vec_get("mx"), h.vec_get("my"), h.vec_get("mz")
+            d = mz - (2.0*mx - 3.0*my)
+            res["lin"] = (float((d*d).sum()), float(((2.0*mx - 3.0*my)**2).sum()))
+            del mx, my, mz, d
+            h.residual()
+            h.copy_residual_to("b")
+            res["fgmres"] = h.fgmres("b", "d")
+            h.spmv("d", "Jd")
+            b = h.vec_get("b")
+            r = h.vec_get("Jd") - b
+            res["true_res"] = (float((r*r).sum()), float((b*b).sum()))
+            del b, r
+            h.close()
+            # the first time step of the reference's time loop with the 42 wells (dt = maxdt*2^-10, halved on divergence)
+            h = E.HipEngine(spec, opts, rank=rank, nranks=nranks, local_group=group)
+            dt = 0.1*86400.0/1024.0
+            for attempt in range(4):
+                h.set_state(u0)
+                h.set_old(None)
+                h.set_dt(dt)
+                info = h.newton_solve()
+                if info["reason"] > 0:             # (identical on every slab: the norms are all-reduced)
+                    break
+                dt *= 0.5
+            res["newton"] = (info["nits"], info["lits"], info["reason"], attempt)
+            res["srange"] = h.saturation_range()
+            h.close()
+            out[rank] = res
+        except Exception as e:      # noqa: BLE001
+            err.append((rank, repr(e)))
+    ts = [threading.Thread(target=worker, args=(r,)) for r in range(nranks)]
+    for t in ts:
+        t.start()
+    for t in ts:
+        t.join(timeout=900)
+    assert not any(t.is_alive() for t in ts), "slab worker hung"
+    lib.tp_local_group_destroy(group)
+    assert not err, err
+    # 8-way distributed top levels: 71.8 M -> ... -> the first level of at most amg_gather_cells = 2 M cells is gathered
+    nd, sched = out[0]["layout"]
+    assert nd >= 5 and all(o["layout"] == out[0]["layout"] for o in out), out[0]["layout"]
+    for f in range(3):              # fluxes cancel over the whole box, slab interfaces included
+        assert abs(sum(o["flux_sum"][f] for o in out)) <= 1e-9*sum(o["flux_abs"][f] for o in out)
+    assert sum(o["lin"][0] for o in out) <= (1e-9)**2*sum(o["lin"][1] for o in out)
+    its, reason, _ = out[0]["fgmres"]
+    assert reason == 2 and all(o["fgmres"][:2] == (its, reason) for o in out), [o["fgmres"] for o in out]
+    assert sum(o["true_res"][0] for o in out) <= (1.5e-8)**2*sum(o["true_res"][1] for o in out)
+    assert all(o["newton"] == out[0]["newton"] for o in out)
+    nits, lits, nreason, attempt = out[0]["newton"]
+    assert nreason > 0 and 0 < nits <= 25, out[0]["newton"]
+    assert min(o["srange"][0] for o in out) >= -1e-6 and max(o["srange"][1] for o in out) <= 1.0 + 1e-6
+    print("c5 full box, 8 slabs: dist levels %d, fgmres(10) %d its, first step: %d Newton / %d Krylov its (dt halvings %d)"
+          % (nd, its, nits, lits, attempt))

@@ -37,6 +37,8 @@ CASES = [
     ("c2_1ph_2d", cases.c3_spe10_2d, dict(Nx=14, Ny=19, nphase=1), dict(pc="cpr", decoup="QI", ilu_tile=(1 << 30, 64, 1))),
     ("c4_2ph_3d", cases.c4_spe10_3d, dict(Nx=7, Ny=13, Nz=9, nphase=2), dict(pc="cptr")),
     ("c4_1ph_3d", cases.c4_spe10_3d, dict(Nx=7, Ny=13, Nz=9, nphase=1), dict(pc="cpr", decoup="TI")),
+    # a plane of fewer than 8 cells (n0*n1 = 6): the multi-wave ILU sweep must fall back from its 8-value block transfers
+    ("c4_2ph_3d_tinyplane", cases.c4_spe10_3d, dict(Nx=3, Ny=14, Nz=2, nphase=2), dict(pc="cptr")),
     ("c4_2ph_3d_cprQI", cases.c4_spe10_3d, dict(Nx=9, Ny=10, Nz=5, nphase=2), dict(pc="cpr", decoup="QI")),
     ("c4_2ph_3d_tiles", cases.c4_spe10_3d, dict(Nx=11, Ny=13, Nz=17, nphase=2), dict(pc="cptr", ilu_tile=(5, 4, 7))),
     ("c4_2ph_3d_fp32amg", cases.c4_spe10_3d, dict(Nx=9, Ny=14, Nz=8, nphase=2), dict(pc="cptr", amg_single=True)),

@@ -9,7 +9,7 @@ import os
 import numpy as np
 
 from .boxgeo import BoxGeo
-from .data.synthetic_spe10 import synthetic_spe10, upsample
+from .data.synthetic_spe10 import kill_cells, synthetic_spe10, upsample
 
 
 class SPE10Model3D(BoxGeo):
@@ -31,10 +31,15 @@ class SPE10Model3D(BoxGeo):
             f = {k: np.load(os.path.join(d, "slice_%s.npy" % k)) for k in names}
             self.data_source = "slice_*.npy in " + d
         else:
-            f = synthetic_spe10(-(-self.Nx//r), -(-self.Ny//r), -(-self.Nz//r), seed=self.seed)
+            # refined models (config 5): K keeps the coarse field's piecewise-constant contrast, the zero-porosity cells
+            # are punched AFTER the refinement (isolated dead cells, as in the unrefined model)
+            f = synthetic_spe10(-(-self.Nx//r), -(-self.Ny//r), -(-self.Nz//r), seed=self.seed, dead=(r == 1))
             self.data_source = "synthetic SPE10-like field, default_rng(%d)" % self.seed
         if r > 1:
             f = upsample(f, r)
+            if not os.path.exists(os.path.join(d, "slice_perm_z.npy")):
+                kill_cells(f["phi"], self.seed + 1)
+                self.data_source += ", refined x%d, dead cells drawn at the fine resolution (default_rng(%d))" % (r, self.seed + 1)
         sl = (slice(0, self.Nx), slice(0, self.Ny), slice(0, self.Nz))
         self.phi = f["phi"][sl] + 1e-10          # removing rock only cells (:28)
         self.K_x = f["perm_x"][sl].copy()

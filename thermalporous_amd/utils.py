@@ -13,12 +13,35 @@ def cell_index(geo, i, j, k=0):
     return i + geo.Nx*(j + geo.Ny*k)
 
 
+def _window(geo, w, half):
+    """Index ranges [lo, hi) per axis of the cells within `half[a]` cells of the cell containing the point w, and the
+    cell-centre coordinates of that window (same expressions as geo.cell_centres(), so the values are bit-identical).
+    Everything a well needs lies in such a window; evaluating the reference's whole-grid expressions on it instead of on
+    every cell makes well set-up O(1) per well (42 wells on the 71.8 M-cell box of config 5: minutes -> milliseconds)."""
+    N = (geo.Nx, geo.Ny, geo.Nz)[:geo.dim]
+    D = (geo.Dx, geo.Dy, getattr(geo, "Dz", 1.0))[:geo.dim]
+    lo, hi, axes = [], [], []
+    for a in range(geo.dim):
+        i = min(max(int(np.floor(w[a]/D[a])), 0), N[a] - 1)
+        lo.append(max(i - half[a], 0))
+        hi.append(min(i + half[a] + 1, N[a]))
+        axes.append((np.arange(lo[a], hi[a]) + 0.5)*D[a])
+    return lo, hi, np.meshgrid(*axes, indexing="ij")
+
+
 def GetNodeClosestToCoordinate(geo, coord):
-    cc = geo.cell_centres()
+    lo, hi, cc = _window(geo, coord, [2]*geo.dim)
     d2 = sum((c - w)**2 for c, w in zip(cc, coord))
-    # flat order x fastest -> transpose so that ravel() runs i fastest
+    # first minimum in flat order (x fastest): transpose so that ravel() runs i fastest, as the whole-grid scan did; a
+    # centre outside the +-2 window is farther away than every centre inside it by more than a cell size -- never a tie
     flat = np.transpose(d2, tuple(range(d2.ndim))[::-1]).ravel()
-    return int(np.argmin(np.sqrt(flat)))     # argmin returns the first minimum
+    m = int(np.argmin(np.sqrt(flat)))
+    shape = [h - l for l, h in zip(lo, hi)]
+    idx, rem = [], m
+    for a in range(geo.dim):
+        idx.append(lo[a] + rem % shape[a])
+        rem //= shape[a]
+    return int(cell_index(geo, *idx))
 
 
 class Delta():
@@ -54,8 +77,11 @@ def well_delta(geo, w):
 def well_circle(geo, w, radius, height=None):
     """Bump exp(-1/(r^2-d^2)) for d<r sampled at cell centres, normalised by its integral;
     3-D adds |z-zw| < height; falls back to well_delta when no centre is inside
-    (wellcase.py:110-123,141-155)."""
-    cc = geo.cell_centres()
+    (wellcase.py:110-123,141-155).  Evaluated on the window of cells that can lie inside (see _window)."""
+    half = [int(np.ceil(radius/geo.Dx)) + 2, int(np.ceil(radius/geo.Dy)) + 2]
+    if geo.dim == 3:
+        half.append(int(np.ceil(height/geo.Dz)) + 2)
+    lo, hi, cc = _window(geo, w, half)
     d2 = (cc[0] - w[0])**2 + (cc[1] - w[1])**2
     inside = d2 < radius**2
     if geo.dim == 3:
@@ -68,6 +94,7 @@ def well_circle(geo, w, radius, height=None):
     normalise = vals.sum()*vol
     if normalise == 0:
         return well_delta(geo, w)
-    cells = cell_index(geo, *idx) if geo.dim == 3 else cell_index(geo, idx[0], idx[1])
+    gidx = [ix + l for ix, l in zip(idx, lo)]
+    cells = cell_index(geo, *gidx) if geo.dim == 3 else cell_index(geo, gidx[0], gidx[1])
     order = np.argsort(cells)
     return Delta(cells[order], (vals/normalise)[order], vol)
