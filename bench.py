@@ -145,6 +145,19 @@ def make_model(name, engine_factory=None, Nxyz=None, **over):
     return cls(geo, case, params, end=1e9, filename=None, verbosity=False, _engine_factory=engine_factory, **kw)
 
 
+_BEAT = [0.0]
+
+
+def heartbeat(what, model, every=30.0):
+    """One progress line on stderr every `every` seconds (rank 0): long runs (config 5) must not look hung to the launcher."""
+    now = time.perf_counter()
+    if now - _BEAT[0] >= every and int(os.environ.get("RANK", "0")) == 0:
+        _BEAT[0] = now
+        print("[bench] %s: time step %d, dt %.4g d, Newton its %d, FGMRES its %d, failed solves %d"
+              % (what, model.i_step, float(model.dt)/86400.0, model.total_nits, model.total_lits, model.failed_solves),
+              file=sys.stderr, flush=True)
+
+
 def spin_up(model, cap):
     """The reference's own dt ramp from maxdt*dt_init_fact up to maxdt (untimed initialisation of the state)."""
     maxdt_s = model.maxdt*86400.0
@@ -153,6 +166,7 @@ def spin_up(model, cap):
     while float(model.dt) < maxdt_s*(1.0 - 1e-12) and n < cap:
         model.step()
         n += 1
+        heartbeat("spin-up", model)
     return n, time.perf_counter() - t0
 
 
@@ -242,6 +256,7 @@ def main():
             "dt_days": [model.dt_vec[0]/86400.0, model.dt_vec[-1]/86400.0] if model.dt_vec else None}
     for _ in range(args.warmup):
         model.step()
+        heartbeat("warm-up", model)
     n0, l0, f0, s0 = model.total_nits, model.total_lits, model.failed_solves, len(model.dt_vec)
     # state at the start of the timed region, for the CPU leg (same state, same dt)
     want_cpu = (not args.no_cpu_baseline) and world == 1
@@ -256,6 +271,7 @@ def main():
     t0 = time.perf_counter()
     for _ in range(args.steps):
         model.step()
+        heartbeat("timed region", model)
     torch.cuda.synchronize()
     parallel.barrier()
     el = time.perf_counter() - t0

@@ -28,7 +28,7 @@ DEFAULT_OPTS = dict(
     fs_additive=False,      # pc_fieldsplit_type additive on (p,T): pc_fieldsplit_diag (singlephase.py:371-375)
     schur_selfp=False,      # pc_fieldsplit_schur_precondition selfp (pc_fieldsplit_selfp, singlephase.py:322-330)
     amg_dom_tau=0.25,       # relaxation-only truncation of diagonally dominant AMG hierarchies (oracle/linalg.py:SemiAMG)
-    amg_gather_cells=2000000,     # GPU multi-slab execution detail (same algebra): ignored here
+    amg_gather_cells=600000,      # GPU multi-slab execution detail (same algebra): ignored here
     ilu_tile=None,          # None: (whole line, 8, 8) in 3-D, (whole line, 32, 1) in 2-D -- the GPU engine's default
     ilu_levels=0,           # sub_1_sub_pc_factor_levels: 0 or 1 (oracle/linalg.py:TiledILU1)
     bjacobi_blocks=None,    # -sub_1_pc_bjacobi_blocks: N boxes over the grid (same rule as the GPU engine, no lane limit)

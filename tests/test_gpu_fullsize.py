@@ -319,11 +319,18 @@ def test_c5_full_box_eight_slabs_in_process():
     slab.  Memory: ~21 GB per slab without the Krylov basis; ksp_restart = 10 keeps the eight bases at 4.8 GB each
     (the default restart of 200 grows the basis on demand and is what an 8-GPU run uses: one slab per 288 GB)."""
     import ctypes as C
+    import sys
     import threading
+    import time
     import bench
     from thermalporous_amd import engine as E
     from thermalporous_amd.problem import build_spec
+    t_start = time.time()
+
+    def say(msg):           # progress on stderr: minutes pass between the phases of this test
+        print("[c5 full box %6.1f s] %s" % (time.time() - t_start, msg), file=sys.stderr, flush=True)
     params, geo, case, cls, kw = bench.build_case("c5")
+    say("fields and wells built")
     spec = build_spec(geo, case, params, 2)
     assert sorted(spec["n"]) == [240, 340, 880] and spec["n"][2] == 880
     del geo, case
@@ -352,11 +359,15 @@ def test_c5_full_box_eight_slabs_in_process():
             res["flux_sum"] = [float(R[f].sum()) for f in range(3)]
             res["flux_abs"] = [float(np.abs(R[f]).sum()) for f in range(3)]
             del R
+            if rank == 0:
+                say("flux residual done")
             h.set_old(u0)
             h.set_state(u)
             h._ck(h.lib.tp_jacobian(h.ctx))
             h.pc_setup()
             res["layout"] = h.amg_layout(0)
+            if rank == 0:
+                say("Jacobian + pc_setup done, layout %r" % (res["layout"],))
             for name, v in (("mx", x), ("my", y), ("mz", z)):
                 h.vec_set("x", v)
                 h.pc_apply("x", name)
@@ -364,6 +375,8 @@ def test_c5_full_box_eight_slabs_in_process():
             d = mz - (2.0*mx - 3.0*my)
             res["lin"] = (float((d*d).sum()), float(((2.0*mx - 3.0*my)**2).sum()))
             del mx, my, mz, d
+            if rank == 0:
+                say("pc_apply linearity done")
             h.residual()
             h.copy_residual_to("b")
             res["fgmres"] = h.fgmres("b", "d")
@@ -372,6 +385,8 @@ def test_c5_full_box_eight_slabs_in_process():
             r = h.vec_get("Jd") - b
             res["true_res"] = (float((r*r).sum()), float((b*b).sum()))
             del b, r
+            if rank == 0:
+                say("fgmres done: %r" % (res["fgmres"],))
             h.close()
             # the first time step of the reference's time loop with the 42 wells (dt = maxdt*2^-10, halved on divergence)
             h = E.HipEngine(spec, opts, rank=rank, nranks=nranks, local_group=group)
@@ -381,6 +396,8 @@ def test_c5_full_box_eight_slabs_in_process():
                 h.set_old(None)
                 h.set_dt(dt)
                 info = h.newton_solve()
+                if rank == 0:
+                    say("newton attempt %d dt %.3g: %r" % (attempt, dt, info))
                 if info["reason"] > 0:             # (identical on every slab: the norms are all-reduced)
                     break
                 dt *= 0.5

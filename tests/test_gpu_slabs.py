@@ -284,3 +284,58 @@ def test_switching_pc_kinds_on_a_live_slab_group(seq_name):
     for k, o in enumerate(seq):
         fresh = _pc_sequence_on_slabs(spec, u0, u, 3000.0, xs, 2, [o])[0]
         assert rel2(got[k], fresh) < 1e-12, (seq_name, k)
+
+
+@pytest.mark.parametrize("gather", [2000000, 0], ids=["replicated", "distributed"])
+def test_pc_apply_program_replay_on_slabs(gather):
+    """Multi-slab pc_apply runs as a recorded PROGRAM: hipGraph segments between the exchanges, the exchanges as host
+    closures (tp_common.hpp).  The recording pass must already produce the result, a replay on the same vector pair must
+    reproduce it bit for bit, and a replay with other CONTENTS in the same buffers must follow them (linearity)."""
+    from thermalporous_amd import engine as E
+    spec, u0, *_ = cases.c4_spe10_3d(Nx=8, Ny=21, Nz=7, nphase=2)
+    u = cases.perturbed_state(spec, seed=5, amp=0.2)
+    xs = np.random.default_rng(11).standard_normal(u.shape)
+    opts = dict(pc="cptr", ksp_rtol=1e-8, amg_gather_cells=gather)
+    nranks = 3
+    lib = E.load_library()
+    group = C.c_void_p()
+    assert lib.tp_local_group_create(nranks, C.byref(group)) == 0
+    out, err = [None]*nranks, []
+
+    def worker(rank):
+        try:
+            h = E.HipEngine(spec, opts, rank=rank, nranks=nranks, local_group=group)
+            h.set_old(u0)
+            h.set_dt(3000.0)
+            h.set_state(u)
+            h.jacobian()
+            h.pc_setup()
+            res = []
+            for fac in (1.0, 1.0, -2.5):          # record, replay, replay with other contents
+                h.vec_set("x", fac*xs)
+                h.pc_apply("x", "y")
+                res.append(h.vec_get("y"))
+            out[rank] = res
+            h.close()
+        except Exception as e:      # noqa: BLE001
+            err.append((rank, repr(e)))
+    ts = [threading.Thread(target=worker, args=(r,)) for r in range(nranks)]
+    for t in ts:
+        t.start()
+    for t in ts:
+        t.join(timeout=300)
+    assert not any(t.is_alive() for t in ts), "slab worker hung"
+    lib.tp_local_group_destroy(group)
+    assert not err, err
+    y1, y2, y3 = (np.concatenate([o[k] for o in out], axis=-3) for k in range(3))
+    assert np.array_equal(y1, y2)
+    assert rel2(y3, -2.5*y1) < 1e-13
+    # and it is the N-slab oracle's preconditioner
+    from oracle.engine import OracleEngine
+    o = OracleEngine(spec, dict(opts, nslabs=nranks))
+    o.set_old(u0)
+    o.set_dt(3000.0)
+    o.set_state(u)
+    J, Sm = o.jacobian(want_schur=True)
+    o.pc.setup(J, Sm)
+    assert rel2(y1, o.pc.apply(xs)) < 1e-9

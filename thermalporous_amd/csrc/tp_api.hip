@@ -56,9 +56,27 @@ static void lg_done(tp_ctx *c) {
 // grid of the array being exchanged (the slab itself, or one of its distributed AMG levels).
 struct HaloPub { const char *p; size_t fstride; int n2; };
 
+// While a pc_apply program is being recorded (tp_solver.hip) an exchange closes the current capture segment (which is
+// instantiated and launched, so the recording pass computes the real result), runs eagerly, is remembered as a host
+// closure, and a new segment is opened behind it.  `call` re-enters the same function with recording suspended.
+#define TP_COMM_RECORD(c, call)                                                     \
+    do {                                                                            \
+        if ((c)->rec && !(c)->rec_in_comm) {                                        \
+            seg_end(c);                                                             \
+            (c)->rec->steps.push_back({nullptr, [=]() { call; }});                  \
+            (c)->rec_in_comm = true;                                                \
+            try { call; } catch (...) { (c)->rec_in_comm = false; throw; }          \
+            (c)->rec_in_comm = false;                                               \
+            seg_begin(c);                                                           \
+            return;                                                                 \
+        }                                                                           \
+    } while (0)
+
+
 void halo_exchange_raw(tp_ctx *c, const GridDev &g, void *x_, int nf, size_t fstride, size_t elem) {
     if (!c->dist) return;
     TP_REQUIRE(g.n2 >= 1, "halo exchange of an empty slab");
+    TP_COMM_RECORD(c, halo_exchange_raw(c, g, x_, nf, fstride, elem));
     char *x = (char *)x_;
     const int lo = c->grid.rank - 1, hi = c->grid.rank + 1;
     const size_t pb = (size_t)g.np * elem;       // bytes per plane
@@ -106,6 +124,7 @@ void halo_exchange(tp_ctx *c, const GridDev &g, double *x, int nf, long fstride)
 void gather_ranges(tp_ctx *c, void *global_, long np, const std::vector<std::pair<int, int>> &ranges, int nslots,
                    size_t slot_stride, size_t elem) {
     TP_REQUIRE(c->dist, "gather_ranges without a communicator");
+    TP_COMM_RECORD(c, gather_ranges(c, global_, np, ranges, nslots, slot_stride, elem));
     char *global = (char *)global_;
     const size_t pb = (size_t)np * elem;
     if (c->lgroup) {
@@ -142,6 +161,7 @@ void slab_of(const tp_ctx *c, int rank, int &lo, int &hi) {
 // array (uneven slabs: one ncclBroadcast per (plane, root) inside one group).
 void gather_slabs(tp_ctx *c, const double *local, long lstride, double *global, long gstride, int nplanes) {
     TP_REQUIRE(c->dist, "gather_slabs without a communicator");
+    TP_COMM_RECORD(c, gather_slabs(c, local, lstride, global, gstride, nplanes));
     const long np = c->g.np;
     if (c->lgroup) {
         // NOTE: lstride is the same on every rank only when it is expressed in this rank's ntot; ranks
@@ -176,6 +196,7 @@ void gather_slabs(tp_ctx *c, const double *local, long lstride, double *global, 
 
 void allreduce_sum(tp_ctx *c, double *dev, int n) {
     if (!c->dist || n <= 0) return;
+    TP_COMM_RECORD(c, allreduce_sum(c, dev, n));
     if (c->lgroup) {
         LocalGroup *G = c->lgroup;
         std::vector<double> &mine = G->red[c->grid.rank];
@@ -197,6 +218,7 @@ void allreduce_sum(tp_ctx *c, double *dev, int n) {
 // element-wise maximum over the ranks (non-negative doubles: the AMG dominance ratios)
 void allreduce_max(tp_ctx *c, double *dev, int n) {
     if (!c->dist || n <= 0) return;
+    TP_COMM_RECORD(c, allreduce_max(c, dev, n));
     if (c->lgroup) {
         LocalGroup *G = c->lgroup;
         std::vector<double> &mine = G->red[c->grid.rank];
@@ -223,6 +245,9 @@ tp_ctx::~tp_ctx() {
     delete amg_T;
     if (bamg) tp::bamg_destroy(bamg);
     for (auto &gph : pc_graphs) (void)hipGraphExecDestroy(gph.exec);
+    for (auto &pr : pc_programs)
+        for (auto &st : pr.steps)
+            if (st.exec) (void)hipGraphExecDestroy(st.exec);
     if (comm) ncclCommDestroy((ncclComm_t)comm);
     if (ev0) (void)hipEventDestroy(ev0);
     if (ev1) (void)hipEventDestroy(ev1);

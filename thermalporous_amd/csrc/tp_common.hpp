@@ -7,6 +7,7 @@
 #include <string>
 #include <vector>
 #include <stdexcept>
+#include <functional>
 #include "../../include/thermalporous_hip.h"
 
 struct ncclComm;
@@ -226,6 +227,14 @@ struct tp_ctx {
     // vector j into Z_j, a handful of fixed address pairs that recur in every solve
     struct PcGraph { const double *x; double *y; hipGraphExec_t exec; };
     std::vector<PcGraph> pc_graphs;
+    // multi-GPU: a preconditioner application is recorded as a PROGRAM -- hipGraph segments (the kernel sequences between two
+    // exchanges) alternating with the exchanges themselves (RCCL calls / in-process copies, replayed as host closures on the
+    // same stream).  RCCL calls are never captured; only what lies between them is.
+    struct PcStep { hipGraphExec_t exec; std::function<void()> comm; };
+    struct PcProgram { const double *x; double *y; std::vector<PcStep> steps; };
+    std::vector<PcProgram> pc_programs;
+    PcProgram *rec = nullptr;          // program being recorded (comm calls split the capture), else null
+    bool rec_capturing = false, rec_in_comm = false;
     uint64_t graph_epoch = 1, pc_graph_epoch = 0;
     uintptr_t pc_sig = 0;
     // comm: RCCL communicator (one process per GPU) or an in-process slab group (several contexts on one GPU,
@@ -297,6 +306,9 @@ void gather_ranges(tp_ctx *c, void *global, long np, const std::vector<std::pair
 void allreduce_sum(tp_ctx *c, double *dev, int n);
 void allreduce_max(tp_ctx *c, double *dev, int n);
 void slab_of(const tp_ctx *c, int rank, int &lo, int &hi);
+// recording of pc_apply programs (tp_solver.hip): close / reopen the current stream-capture segment around an exchange
+void seg_begin(tp_ctx *c);
+void seg_end(tp_ctx *c);
 // gather `nplanes` slab-distributed cell planes into arrays on the global grid (every rank gets all slabs)
 void gather_slabs(tp_ctx *c, const double *local, long lstride, double *global, long gstride, int nplanes);
 // solver

@@ -330,6 +330,29 @@ static void pc_apply_body(tp_ctx *c, const double *x, double *y) {
     ilu_solve(c, c->w1.p, y, y, npri);                       // y = y + M^-1 r  (y's secondary fields are zero: not read)
 }
 
+// ---- recording of multi-GPU pc_apply programs: one capture segment between two exchanges -------------------------------
+void seg_begin(tp_ctx *c) {
+    TP_HIP(hipStreamBeginCapture(c->stream, hipStreamCaptureModeThreadLocal));
+    c->rec_capturing = true;
+}
+// closes the segment; a non-empty one is instantiated, appended to the program and LAUNCHED (a capture executes nothing: the
+// recording pass must still produce the result, and the exchange that follows reads what these kernels wrote)
+void seg_end(tp_ctx *c) {
+    hipGraph_t graph = nullptr;
+    c->rec_capturing = false;
+    TP_HIP(hipStreamEndCapture(c->stream, &graph));
+    size_t nnodes = 0;
+    TP_HIP(hipGraphGetNodes(graph, nullptr, &nnodes));
+    if (nnodes > 0) {
+        hipGraphExec_t exec = nullptr;
+        const hipError_t e = hipGraphInstantiate(&exec, graph, nullptr, nullptr, 0);
+        if (e != hipSuccess) { (void)hipGraphDestroy(graph); TP_HIP(e); }
+        c->rec->steps.push_back({exec, nullptr});
+        TP_HIP(hipGraphLaunch(exec, c->stream));
+    }
+    TP_HIP(hipGraphDestroy(graph));
+}
+
 // One preconditioner application is ~100 short kernels (the V-cycles' coarse levels); issued eagerly
 // the host launch path (~3 us per kernel) is slower than the GPU executes them.  The whole sequence
 // is therefore captured into a hipGraph per (input, output) address pair -- FGMRES uses the fixed pairs
@@ -340,14 +363,50 @@ void pc_apply(tp_ctx *c, const double *x, double *y) {
     c->vcycles += c->opt.pc_kind == 4 ? 0 : c->opt.fs_additive ? 2 : schur_of(c->opt) ? 3 : 1;
     ensure_work(c);                      // never allocate inside a stream capture
     resolve_cycle_shapes(c);             // (waits for the last set-up's dominance ratios: not inside a capture either)
-    if (!use_graph || c->dist) {
+    if (!use_graph) {
         pc_apply_body(c, x, y);
         return;
     }
-    if (c->pc_graph_epoch != c->graph_epoch || c->pc_graphs.size() > 512) {      // stale (or runaway) cache
+    if (c->pc_graph_epoch != c->graph_epoch || c->pc_graphs.size() > 512 || c->pc_programs.size() > 512) {      // stale (or runaway) cache
         for (auto &gph : c->pc_graphs) (void)hipGraphExecDestroy(gph.exec);
         c->pc_graphs.clear();
+        for (auto &pr : c->pc_programs)
+            for (auto &st : pr.steps)
+                if (st.exec) (void)hipGraphExecDestroy(st.exec);
+        c->pc_programs.clear();
         c->pc_graph_epoch = c->graph_epoch;
+    }
+    if (c->dist) {
+        // several GPUs: graph segments between the exchanges, the exchanges themselves as host closures (tp_common.hpp)
+        for (auto &pr : c->pc_programs)
+            if (pr.x == x && pr.y == y) {
+                for (auto &st : pr.steps) {
+                    if (st.exec) TP_HIP(hipGraphLaunch(st.exec, c->stream));
+                    else st.comm();
+                }
+                return;
+            }
+        c->pc_programs.push_back({x, y, {}});
+        c->rec = &c->pc_programs.back();
+        try {
+            seg_begin(c);
+            pc_apply_body(c, x, y);
+            seg_end(c);
+        } catch (...) {
+            if (c->rec_capturing) {
+                hipGraph_t g = nullptr;
+                (void)hipStreamEndCapture(c->stream, &g);
+                if (g) (void)hipGraphDestroy(g);
+                c->rec_capturing = false;
+            }
+            for (auto &st : c->pc_programs.back().steps)
+                if (st.exec) (void)hipGraphExecDestroy(st.exec);
+            c->pc_programs.pop_back();
+            c->rec = nullptr;
+            throw;
+        }
+        c->rec = nullptr;
+        return;
     }
     // TP_DEBUG=2: one line per HIP graph call (used to locate the profiler crash described in DESIGN.md 6)
     static const bool trace = getenv("TP_DEBUG") && atoi(getenv("TP_DEBUG")) >= 2;

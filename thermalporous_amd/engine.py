@@ -72,7 +72,11 @@ DEFAULT_OPTS = dict(
     snes_rtol=1e-8, snes_atol=1e-50, snes_stol=1e-8, snes_max_it=15,
     amg_omega=0.8, amg_min_cells=64, amg_nu=2, amg_full_levels=3, amg_coarse_pre=0, amg_coarse_post=1, amg_mid_skip=True, amg_tail_post=2, amg_single=False,
     amg_dom_tau=0.25,       # relaxation-only truncation of diagonally dominant AMG hierarchies (oracle/linalg.py:SemiAMG)
-    amg_gather_cells=2000000,
+    # multi-GPU: AMG levels with more cells than this stay distributed over the slabs.  Cost model: a V(2,2)
+    # level streams ~6 sweeps x 104 B per cell (5.5 TB/s on one GPU) and needs 6 halo exchanges when distributed; with N
+    # slabs it saves (1 - 1/N) of its streaming time and pays 6 x t_exchange (~10 us per grouped RCCL send/recv): the
+    # break-even is ~0.6 M cells, so C4's level 0 (1.12 M cells) is distributed, its level 1 (0.56 M) is gathered
+    amg_gather_cells=600000,
     schur_a11=False,
     fs_additive=False,      # pc_fieldsplit_type additive on (p,T): pc_fieldsplit_diag (singlephase.py:371-375)
     schur_selfp=False,      # pc_fieldsplit_schur_precondition selfp (pc_fieldsplit_selfp, singlephase.py:322-330)
