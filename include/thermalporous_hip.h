@@ -107,6 +107,10 @@ typedef struct tp_options {
                                 take 4 steps of skew per axis-2 plane and 2 per axis-1 line instead of 1 and 1 */
     int32_t fs_additive;     /* pc_kind 2: 1 = PCFIELDSPLIT additive on (p,T) -- y_p = V(A_pp) x_p, y_T = V(A_TT) x_T, no coupling
                                 (pc_fieldsplit_diag, singlephase.py:371-375) -- instead of Schur FULL */
+    int32_t ilu_whole;       /* 1: ONE bjacobi block per rank = block-ILU(0) of the whole slab, PETSc's default bjacobi and the
+                                reference's `sub_1_pc_bjacobi_blocks: 1` (tests/test_homo_wells.py:112, pc_cptr_a11
+                                twophase.py:612): couplings between the tiles are kept; the tiles (ilu_t0 x ilu_t1 x ilu_t2,
+                                now only the unit of the sweep) are swept one tile-diagonal T0+T1+T2 per launch.  ILU(0) only. */
 } tp_options;
 
 /* Result of one nonlinear solve (SNES iteration number / linear iterations / reason:

@@ -104,6 +104,8 @@ class CPortEngine:
         if o.get("bjacobi_blocks") is not None:
             from ..engine import blocks_to_tile
             o["ilu_tile"] = blocks_to_tile(spec["n"], o["bjacobi_blocks"])
+        if o.get("ilu_whole"):                   # one bjacobi block per slab: ILU(0) of the whole slab
+            o["ilu_tile"] = (1 << 30, 1 << 30, 1 << 30)
         if o.get("ilu_tile") is None:
             from ..engine import default_ilu_tile
             o["ilu_tile"] = default_ilu_tile(spec["n"], nslabs=int(o.get("nslabs", 1)))

@@ -32,6 +32,7 @@ DEFAULT_OPTS = dict(
     ilu_tile=None,          # None: (whole line, 8, 8) in 3-D, (whole line, 32, 1) in 2-D -- the GPU engine's default
     ilu_levels=0,           # sub_1_sub_pc_factor_levels: 0 or 1 (oracle/linalg.py:TiledILU1)
     bjacobi_blocks=None,    # -sub_1_pc_bjacobi_blocks: N boxes over the grid (same rule as the GPU engine, no lane limit)
+    ilu_whole=False,        # one bjacobi block per slab (the GPU engine's whole-slab ILU(0))
 )
 
 
@@ -103,6 +104,8 @@ class OracleEngine:
         self.u = None
         if self.opts.get("bjacobi_blocks") is not None:
             self.opts["ilu_tile"] = blocks_to_tile(spec["n"], self.opts["bjacobi_blocks"])
+        if self.opts.get("ilu_whole"):           # one bjacobi block per slab: ILU(0) of the whole slab
+            self.opts["ilu_tile"] = (1 << 30, 1 << 30, 1 << 30)
         if self.opts.get("ilu_tile") is None:
             self.opts["ilu_tile"] = default_ilu_tile(spec["n"], nslabs=int(self.opts.get("nslabs", 1)))
         self.pc = la.TwoStagePC(self.prob, self.opts)

@@ -157,6 +157,29 @@ def test_two_phase_ilu1_preset_time_loop():
         assert rel2(a, b) < 1e-7
 
 
+def test_two_phase_cptr_a11_preset_time_loop():
+    """pc_cptr_a11 (twophase.py:598-616) AS WRITTEN in the reference -- Schur complement preconditioned by A_11 and
+    ``sub_1_pc_bjacobi_blocks: 1`` (:612): one bjacobi block = whole-grid ILU(0) -- through TwoPhase.solve() on the HIP engine
+    (whole-slab ILU(0) as tile-diagonal sweeps, tp_options.ilu_whole) vs the oracle engine (one tile = the grid).  The grid
+    has 13 x 9 = 117 columns: more than one wavefront, so the round-2 engine raised NotImplementedError here."""
+    from oracle.engine import OracleEngine
+    from thermalporous_amd.twophase import TwoPhase
+    res = []
+    for factory in (OracleEngine, None):
+        spec, u0, p, g, c = cases.c4_spe10_3d(Nx=13, Ny=17, Nz=9, nphase=2)
+        m = TwoPhase(g, c, p, end=0.02, maxdt=0.01, small_dt_start=False, solver_parameters="pc_cptr_a11",
+                     filename=None, verbosity=False, _engine_factory=factory)
+        assert m.engine_opts["bjacobi_blocks"] == 1 and m.engine_opts["schur_a11"] is True and m.engine_opts["pc"] == "cptr"
+        m.solve()
+        if factory is None:
+            assert m.engine.opts["ilu_whole"] is True
+        res.append((m.nits_vec, m.lits_vec, [d.copy() for d in m.u.dat.data_ro]))
+    assert res[0][0] == res[1][0] and len(res[0][0]) >= 2
+    assert all(abs(a - b) <= 1 for a, b in zip(res[0][1], res[1][1]))
+    for a, b in zip(res[1][2], res[0][2]):
+        assert rel2(a, b) < 1e-7
+
+
 def test_full_size_properties_c4():
     """BASELINE config 4 at full size (60x220x85): size-independent properties of the GPU path --
     pairwise cancellation of the face fluxes, linearity of every preconditioner stage, and the true

@@ -74,6 +74,15 @@ CASES = [
     ("c3_2ph_2d_ilu1", cases.c3_spe10_2d, dict(Nx=14, Ny=19, nphase=2), dict(pc="cpr", ilu_levels=1, ilu_tile=(1 << 30, 64, 1))),
     ("c2_1ph_2d_ilu1", cases.c3_spe10_2d, dict(Nx=14, Ny=19, nphase=1), dict(pc="cpr", decoup="QI", ilu_levels=1, ilu_tile=(6, 5, 1))),
     ("c4_1ph_3d_ilu1", cases.c4_spe10_3d, dict(Nx=7, Ny=13, Nz=9, nphase=1), dict(pc="cpr", decoup="TI", ilu_levels=1, ilu_tile=(1 << 30, 8, 8))),
+    # ONE bjacobi block = block-ILU(0) of the whole grid (sub_1_pc_bjacobi_blocks: 1, tests/test_homo_wells.py:112; pc_cptr_a11
+    # twophase.py:612): tiles keep their couplings and are swept tile-diagonal by tile-diagonal; partial tiles on every axis,
+    # axis-0 cuts, 2-D, 2x2 blocks, per-step and block vector transfers (the oracle's ILU has one tile = the grid)
+    ("c4_2ph_3d_whole", cases.c4_spe10_3d, dict(Nx=11, Ny=13, Nz=17, nphase=2), dict(pc="cptr", ilu_whole=True, ilu_tile=(5, 4, 7))),
+    ("c4_2ph_3d_whole_dflt", cases.c4_spe10_3d, dict(Nx=9, Ny=22, Nz=37, nphase=2), dict(pc="cptr", bjacobi_blocks=1)),
+    ("c4_1ph_3d_whole", cases.c4_spe10_3d, dict(Nx=7, Ny=13, Nz=9, nphase=1), dict(pc="cpr", decoup="QI", ilu_whole=True, ilu_tile=(1 << 30, 3, 4))),
+    ("c3_2ph_2d_whole", cases.c3_spe10_2d, dict(Nx=14, Ny=19, nphase=2), dict(pc="cptr", ilu_whole=True, ilu_tile=(6, 5, 1))),
+    ("c2_1ph_2d_whole", cases.c3_spe10_2d, dict(Nx=30, Ny=70, nphase=1), dict(pc="cpr", bjacobi_blocks=1)),
+    ("c4_2ph_3d_cptr_a11_whole", cases.c4_spe10_3d, dict(Nx=7, Ny=8, Nz=6, nphase=2), dict(pc="cptr", schur_a11=True, bjacobi_blocks=1)),
     # single-phase block preconditioner pc_fieldsplit_cd (singlephase.py:309-319): ConvDiffSchurPC operator
     ("c4_1ph_3d_fscd", cases.c4_spe10_3d, dict(Nx=7, Ny=13, Nz=9, nphase=1), dict(pc="fieldsplit_cd")),
     ("c2_1ph_2d_fscd", cases.c3_spe10_2d, dict(Nx=14, Ny=19, nphase=1), dict(pc="fieldsplit_cd")),

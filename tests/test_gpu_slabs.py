@@ -162,6 +162,9 @@ SLAB_CASES = [
      dict(pc="cptr", ksp_rtol=1e-8, snes_max_it=25, amg_gather_cells=0), [40.0, 80.0]),
     ("1ph_cprTI_distamg", cases.c4_spe10_3d, dict(Nx=6, Ny=17, Nz=5, nphase=1),
      dict(pc="cpr", decoup="TI", ksp_rtol=1e-8, amg_gather_cells=100), [400.0]),
+    # one bjacobi block per slab (PETSc's default bjacobi): whole-slab ILU(0) on every rank
+    ("2ph_cptr_whole", cases.c4_spe10_3d, dict(Nx=8, Ny=21, Nz=7, nphase=2),
+     dict(pc="cptr", ksp_rtol=1e-8, snes_max_it=25, ilu_whole=True, ilu_tile=(4, 3, 3)), [40.0, 80.0]),
 ]
 
 

@@ -321,7 +321,7 @@ int tp_create(const tp_grid *grid, const tp_params *prm, const tp_options *opt, 
     c->gfull = make_grid(grid->n0, grid->n1, grid->gn2, grid->gn2, 0);
     c->vol = grid->h[0] * grid->h[1] * grid->h[2];
     derive_params(c);
-    TP_HIP(hipStreamCreate(&c->stream));
+    TP_HIP(hipStreamCreateWithFlags(&c->stream, hipStreamNonBlocking));      // (never tied to the legacy stream: tp_common.hpp)
     for (int i = 0; i < 2; ++i) {
         TP_HIP(hipStreamCreateWithFlags(&c->aux[i], hipStreamNonBlocking));
         TP_HIP(hipEventCreateWithFlags(&c->ev_join[i], hipEventDisableTiming));
@@ -343,7 +343,11 @@ int tp_destroy(tp_ctx *ctx) {
     TP_API_BEGIN
     if (ctx) {
         (void)hipSetDevice(ctx->device);
-        (void)hipDeviceSynchronize();
+        // (this context's streams only: a device-wide synchronisation would wait for -- and, while one of them captures, fail on --
+        // the other slab contexts of an in-process group)
+        if (ctx->stream) (void)hipStreamSynchronize(ctx->stream);
+        for (int i = 0; i < 2; ++i)
+            if (ctx->aux[i]) (void)hipStreamSynchronize(ctx->aux[i]);
         delete ctx;
     }
     TP_API_END
@@ -354,7 +358,7 @@ int tp_set_options(tp_ctx *c, const tp_options *opt) {
     TP_REQUIRE(c && opt, "null argument");
     TP_REQUIRE(opt->ilu_levels == 0 || opt->ilu_levels == 1, "ilu_levels must be 0 or 1");
     const bool tile_changed = opt->ilu_t1 != c->opt.ilu_t1 || opt->ilu_t2 != c->opt.ilu_t2 || opt->ilu_t0 != c->opt.ilu_t0 ||
-                              opt->ilu_levels != c->opt.ilu_levels;
+                              opt->ilu_levels != c->opt.ilu_levels || opt->ilu_whole != c->opt.ilu_whole;
     const bool amg_changed = opt->amg_min_cells != c->opt.amg_min_cells || opt->pc_kind != c->opt.pc_kind ||
                              opt->amg_nu != c->opt.amg_nu || opt->amg_full_levels != c->opt.amg_full_levels ||
                              opt->amg_coarse_pre != c->opt.amg_coarse_pre || opt->amg_coarse_post != c->opt.amg_coarse_post ||
@@ -442,7 +446,7 @@ int tp_set_field(tp_ctx *c, const char *name, const double *host, int64_t n) {
     else if (s == "K1") dst = &c->K[1];
     else if (s == "K2") dst = &c->K[2];
     TP_REQUIRE(dst, "unknown field name (phi, kT, K0, K1, K2)");
-    TP_HIP(hipMemcpy(dst->p, host, sizeof(double) * n, hipMemcpyHostToDevice));
+    copy_sync(c, dst->p, host, sizeof(double) * n, hipMemcpyHostToDevice);
     c->fields_ready = false;
     TP_API_END
 }
@@ -479,15 +483,15 @@ int tp_set_sources(tp_ctx *c, int32_t n, const tp_source *entries) {
     c->src.alloc(std::max(1, n));
     c->src_start.alloc(start.size());
     c->rates.alloc((size_t)3 * std::max(1, n));
-    if (n) TP_HIP(hipMemcpy(c->src.p, v.data(), sizeof(tp_source) * n, hipMemcpyHostToDevice));
-    TP_HIP(hipMemcpy(c->src_start.p, start.data(), sizeof(int) * start.size(), hipMemcpyHostToDevice));
+    if (n) copy_sync(c, c->src.p, v.data(), sizeof(tp_source) * n, hipMemcpyHostToDevice);
+    copy_sync(c, c->src_start.p, start.data(), sizeof(int) * start.size(), hipMemcpyHostToDevice);
     TP_API_END
 }
 
 int tp_set_state(tp_ctx *c, const double *u_host) {
     TP_API_BEGIN
     TP_REQUIRE(c && u_host, "null argument");
-    TP_HIP(hipMemcpy(c->u.p, u_host, sizeof(double) * c->u.n, hipMemcpyHostToDevice));
+    copy_sync(c, c->u.p, u_host, sizeof(double) * c->u.n, hipMemcpyHostToDevice);
     TP_API_END
 }
 
@@ -495,7 +499,7 @@ int tp_get_state(tp_ctx *c, double *u_host) {
     TP_API_BEGIN
     TP_REQUIRE(c && u_host, "null argument");
     TP_HIP(hipStreamSynchronize(c->stream));
-    TP_HIP(hipMemcpy(u_host, c->u.p, sizeof(double) * c->u.n, hipMemcpyDeviceToHost));
+    copy_sync(c, u_host, c->u.p, sizeof(double) * c->u.n, hipMemcpyDeviceToHost);
     TP_API_END
 }
 
@@ -503,7 +507,7 @@ int tp_set_old_state(tp_ctx *c, const double *u_host) {
     TP_API_BEGIN
     TP_REQUIRE(c, "null argument");
     TP_REQUIRE(c->fields_ready, "fields not finalised");
-    if (u_host) TP_HIP(hipMemcpy(c->u_old.p, u_host, sizeof(double) * c->u.n, hipMemcpyHostToDevice));
+    if (u_host) copy_sync(c, c->u_old.p, u_host, sizeof(double) * c->u.n, hipMemcpyHostToDevice);
     else vec_copy(c, c->u.p, c->u_old.p, (long)c->u.n);
     accum_old(c);
     c->have_old = true;
@@ -521,7 +525,7 @@ int tp_get_old_state(tp_ctx *c, double *u_host) {
     TP_API_BEGIN
     TP_REQUIRE(c && u_host, "null argument");
     TP_HIP(hipStreamSynchronize(c->stream));
-    TP_HIP(hipMemcpy(u_host, c->u_old.p, sizeof(double) * c->u_old.n, hipMemcpyDeviceToHost));
+    copy_sync(c, u_host, c->u_old.p, sizeof(double) * c->u_old.n, hipMemcpyDeviceToHost);
     TP_API_END
 }
 
@@ -568,7 +572,7 @@ int tp_jacobian(tp_ctx *c) {
 int tp_get_residual(tp_ctx *c, double *host) {
     TP_API_BEGIN
     TP_HIP(hipStreamSynchronize(c->stream));
-    TP_HIP(hipMemcpy(host, c->R.p, sizeof(double) * c->R.n, hipMemcpyDeviceToHost));
+    copy_sync(c, host, c->R.p, sizeof(double) * c->R.n, hipMemcpyDeviceToHost);
     TP_API_END
 }
 
@@ -576,7 +580,7 @@ int tp_export_jacobian(tp_ctx *c, double *host) {
     TP_API_BEGIN
     TP_REQUIRE(c->jac_ready, "Jacobian not assembled");
     TP_HIP(hipStreamSynchronize(c->stream));
-    TP_HIP(hipMemcpy(host, c->J.p, sizeof(double) * c->J.n, hipMemcpyDeviceToHost));
+    copy_sync(c, host, c->J.p, sizeof(double) * c->J.n, hipMemcpyDeviceToHost);
     TP_API_END
 }
 
@@ -584,7 +588,7 @@ int tp_export_schur(tp_ctx *c, double *host) {
     TP_API_BEGIN
     TP_REQUIRE(c->Sm.n > 0 && c->jac_ready, "S~ not assembled (pc_cptr only)");
     TP_HIP(hipStreamSynchronize(c->stream));
-    TP_HIP(hipMemcpy(host, c->Sm.p, sizeof(double) * c->Sm.n, hipMemcpyDeviceToHost));
+    copy_sync(c, host, c->Sm.p, sizeof(double) * c->Sm.n, hipMemcpyDeviceToHost);
     TP_API_END
 }
 
@@ -594,9 +598,9 @@ int tp_well_rates(tp_ctx *c, double *rate, double *water_rate, double *oil_rate)
     well_rates(c);
     TP_HIP(hipStreamSynchronize(c->stream));
     const size_t n = c->nsrc;
-    if (rate) TP_HIP(hipMemcpy(rate, c->rates.p, sizeof(double) * n, hipMemcpyDeviceToHost));
-    if (water_rate) TP_HIP(hipMemcpy(water_rate, c->rates.p + n, sizeof(double) * n, hipMemcpyDeviceToHost));
-    if (oil_rate) TP_HIP(hipMemcpy(oil_rate, c->rates.p + 2 * n, sizeof(double) * n, hipMemcpyDeviceToHost));
+    if (rate) copy_sync(c, rate, c->rates.p, sizeof(double) * n, hipMemcpyDeviceToHost);
+    if (water_rate) copy_sync(c, water_rate, c->rates.p + n, sizeof(double) * n, hipMemcpyDeviceToHost);
+    if (oil_rate) copy_sync(c, oil_rate, c->rates.p + 2 * n, sizeof(double) * n, hipMemcpyDeviceToHost);
     TP_API_END
 }
 
@@ -674,7 +678,7 @@ int tp_vec_norm2(tp_ctx *c, int32_t x, double *out) {
 int tp_vec_set(tp_ctx *c, int32_t id, const double *host) {
     TP_API_BEGIN
     DBuf<double> &v = vec_of(c, id);
-    TP_HIP(hipMemcpy(v.p, host, sizeof(double) * v.n, hipMemcpyHostToDevice));
+    copy_sync(c, v.p, host, sizeof(double) * v.n, hipMemcpyHostToDevice);
     TP_API_END
 }
 
@@ -682,7 +686,7 @@ int tp_vec_get(tp_ctx *c, int32_t id, double *host) {
     TP_API_BEGIN
     DBuf<double> &v = vec_of(c, id);
     TP_HIP(hipStreamSynchronize(c->stream));
-    TP_HIP(hipMemcpy(host, v.p, sizeof(double) * v.n, hipMemcpyDeviceToHost));
+    copy_sync(c, host, v.p, sizeof(double) * v.n, hipMemcpyDeviceToHost);
     TP_API_END
 }
 

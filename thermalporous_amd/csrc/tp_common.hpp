@@ -108,8 +108,12 @@ struct DBuf {
         free();
         n = n_;
         if (n) {
+            // (zeroed on the per-thread stream, complete on return.  Nothing in the library uses the LEGACY default stream: a
+            // legacy-stream operation synchronises with every blocking stream of the device and is an error -- "would make the
+            // legacy stream depend on a capturing blocking stream" -- while any other slab thread is capturing its pc_apply)
             TP_HIP(hipMalloc((void **)&p, n * sizeof(T)));
-            TP_HIP(hipMemset(p, 0, n * sizeof(T)));
+            TP_HIP(hipMemsetAsync(p, 0, n * sizeof(T), hipStreamPerThread));
+            TP_HIP(hipStreamSynchronize(hipStreamPerThread));
         }
     }
     // a slice of somebody else's allocation (zeroed by its owner)
@@ -179,6 +183,14 @@ struct IluData {
     long slots = 0;                // ntiles*nsteps*64
     bool mw = false;               // ILU(0): factor stored in the row-major layout of the multi-wave sweep (tp_ilu.hip)
     int levels = 0;                // 0: ILU(0), 1: ILU(1) (tp_options.ilu_levels; other chunk layout, see tp_ilu.hip)
+    // tp_options.ilu_whole: one block per rank.  Tiles keep their couplings; tile-diagonal d = T0+T1+T2 is one launch:
+    // tiles diag_tiles[diag_off[d] .. diag_off[d+1]) (device array); xtmp: the raw backward-sweep result of every
+    // (tile, step, lane) for the tiles of later launches (x itself may already hold addto + result)
+    bool whole = false;
+    int ndiag = 0;
+    std::vector<int> diag_off;
+    DBuf<int> diag_tiles;
+    DBuf<double> xtmp;
 };
 
 }  // namespace tp
@@ -252,6 +264,12 @@ struct tp_ctx {
 };
 
 namespace tp {
+// Host <-> device copy ordered on the context's stream (after everything queued there) and complete on return.  The context's
+// streams are non-blocking and no call goes to the legacy default stream (see DBuf::alloc).
+inline void copy_sync(tp_ctx *c, void *dst, const void *src, size_t bytes, hipMemcpyKind kind) {
+    TP_HIP(hipMemcpyAsync(dst, src, bytes, kind, c->stream));
+    TP_HIP(hipStreamSynchronize(c->stream));
+}
 // ---- launch wrappers implemented in the .hip files ------------------------------------------------
 // assembly
 void compute_trans(tp_ctx *c);

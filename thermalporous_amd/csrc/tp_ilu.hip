@@ -74,6 +74,7 @@ struct IluGeom {
     int ntiles;    // nt0*nt1*nt2
     int nl;        // lanes of a wave that carry a column: t1*t2 <= 64
     int rs;        // doubles per chunk row: 2*nl when the rows are as wide as the tile (CP kernels), else 128
+    int ws;        // whole-slab ILU(0) (tp_options.ilu_whole): couplings between tiles are kept
 };
 
 // number of double2 pairs per chunk
@@ -140,8 +141,14 @@ __global__ __launch_bounds__(64 * ILU_SEG) void k_ilu_gather(IluGeom G, const do
     int l0;
     long c;
     const bool ok = tile_cell(G, ti, s, l0, c);
-    // which of the 7 blocks survive: couplings to cells outside the tile are dropped (bjacobi)
-    const bool keep[7] = {true, l0 > 0, l0 < ti.tt0 - 1, ti.j > 0, ti.j < ti.tj - 1, ti.k > 0, ti.k < ti.tk - 1};
+    // which of the 7 blocks survive: couplings to cells outside the tile are dropped (bjacobi) -- outside the SLAB when the
+    // whole slab is one block (G.ws)
+    const int g0 = ti.base0 + l0, g1 = ti.base1 + ti.j, g2 = ti.base2 + ti.k;
+    const bool ws = G.ws != 0;
+    const bool keep[7] = {true,
+                          ws ? g0 > 0 : l0 > 0, ws ? g0 < G.g.n0 - 1 : l0 < ti.tt0 - 1,
+                          ws ? g1 > 0 : ti.j > 0, ws ? g1 < G.g.n1 - 1 : ti.j < ti.tj - 1,
+                          ws ? g2 > 0 : ti.k > 0, ws ? g2 < G.g.n2 - 1 : ti.k < ti.tk - 1};
     double v[2 * ILU_PPT];
 #pragma unroll
     for (int u = 0; u < 2 * ILU_PPT; ++u) {          // all loads of the thread in flight together
@@ -162,9 +169,9 @@ __global__ __launch_bounds__(64 * ILU_SEG) void k_ilu_gather(IluGeom G, const do
 // [tile][step][row r][entry (a, q)][lane] -- forward 3B entries per row (B_a[r][q]), backward 4B (C_a[r][q], then D~^-1[r][q])
 template <int B, bool CP, bool MW>
 __global__ __launch_bounds__(64) void k_ilu_factor(IluGeom G, const double *__restrict__ Jt, double *fwd,
-                                                   double *bwd) {
+                                                   double *bwd, const int *__restrict__ tiles) {
     using L = IluLayout<B>;
-    const int tile = blockIdx.x, lane = threadIdx.x;
+    const int tile = tiles ? tiles[blockIdx.x] : blockIdx.x, lane = threadIdx.x;      // (tiles: one tile-diagonal, G.ws)
     const int NL = CP ? G.nl : 64, RS = CP ? G.rs : 128;
     // idle lanes (>= t1*t2) load a live lane's data and store nothing.  With wave-wide rows every lane is live and both
     // are compile-time facts: a (never false) run-time `if (live)` around the stores is a divergent branch to the
@@ -240,6 +247,34 @@ __global__ __launch_bounds__(64) void k_ilu_factor(IluGeom G, const double *__re
             }
         double D[B][B], Di[B][B];
         constexpr int PFR = (3 * B + 1) / 2, PBR = (4 * B + 1) / 2;       // (IluMwLayout)
+        if (MW && G.ws) {
+            // whole-slab ILU(0): a lower neighbour in ANOTHER tile (finished in an earlier launch: smaller T0+T1+T2) is not
+            // in this wave's registers.  Its D~^-1 comes from that tile's backward chunk, its A_mc from the re-ordered
+            // Jacobian.  Lower neighbour tiles are never partial along the axis they are crossed in.
+            int l0c;
+            long ccell;
+            const bool okc = tile_cell(G, ti, s, l0c, ccell);
+            const int T0 = tile % G.nt0, T1 = (tile / G.nt0) % G.nt1, T2 = tile / (G.nt0 * G.nt1);
+#pragma unroll
+            for (int a = 0; a < 3; ++a) {
+                const bool cross = okc && (a == 0 ? (l0c == 0 && T0 > 0) : a == 1 ? (ti.j == 0 && T1 > 0) : (ti.k == 0 && T2 > 0));
+                if (cross) {
+                    const int tA = tile - (a == 0 ? 1 : a == 1 ? G.nt0 : G.nt0 * G.nt1);
+                    const int lnA = a == 0 ? lane : a == 1 ? (G.t1 - 1) + G.t1 * ti.k : ti.j + G.t1 * (G.t2 - 1);
+                    const int sA = a == 0 ? (G.t0 - 1) + ti.j + ti.k : a == 1 ? l0c + (G.t1 - 1) + ti.k : l0c + ti.j + (G.t2 - 1);
+                    const double *bA = bwd + chunk_idx(G, tA, sA) * ((long)2 * B * PBR * G.nl);
+                    const double *jA = Jt + chunk_idx(G, tA, sA) * ((long)L::PJ * RS);
+#pragma unroll
+                    for (int r = 0; r < B; ++r)
+#pragma unroll
+                        for (int q = 0; q < B; ++q) {
+                            Dn[a][r][q] = bA[((long)(r * PBR + ((3 * B + q) >> 1)) * G.nl + lnA) * 2 + ((3 * B + q) & 1)];
+                            const int e = ((2 + 2 * a) * B + r) * B + q;
+                            Amc[a][r][q] = jA[(long)(e >> 1) * RS + lnA * 2 + (e & 1)];
+                        }
+                }
+            }
+        }
         double *fch = fwd + chunk_idx(G, tile, s) * (MW ? (long)2 * B * PFR * G.nl : (long)L::PF * RS);
         double *bch = bwd + chunk_idx(G, tile, s) * (MW ? (long)2 * B * PBR * G.nl : (long)L::PB * RS);
         const bool mlive = lane < G.nl;
@@ -554,16 +589,22 @@ template <int B> struct IluMwLayout {
 // register arrays they capture by reference then live in scratch memory, and the sweep is ten times slower.)
 // BLK: grid-layout vectors moved in blocks of RF / RB steps (below); off for the short 2-D tiles, where the delayed block stores
 // only lengthen the tail
-template <int B, bool YLDS, bool BLK>
+// WS (tp_options.ilu_whole): the whole slab is ONE block.  A launch sweeps the tiles of one tile-diagonal (`tiles`), forward
+// (phase 1) or backward (phase 2); a neighbour value across a tile face was produced by an EARLIER launch and is read from
+// global memory -- y from ytmp, the raw backward result from xtmp -- instead of the LDS.  WS implies !YLDS.
+template <int B, bool YLDS, bool BLK, bool WS = false>
 __global__ __launch_bounds__(64 * B) void k_ilu_solve_mw(IluGeom G, const double *__restrict__ fwd,
                                                          const double *__restrict__ bwd, const double *__restrict__ rhs,
-                                                         double *__restrict__ ytmp, double *x, const double *addto, int nadd) {
+                                                         double *ytmp, double *x, const double *addto, int nadd,
+                                                         const int *__restrict__ tiles = nullptr, int phase = 3,
+                                                         double *xtmp = nullptr) {
+    static_assert(!(WS && YLDS), "whole-slab sweeps keep y in global memory");
     extern __shared__ double lds[];
     using M = IluMwLayout<B>;
     // ring depths: a wave may have 63 loads in flight; what the sweep's throughput follows is BYTES in flight per CU
     // (B waves x ring x 16-byte loads: 3 x 8 x 6 x 864 B = 124 KB on C4, against 44 KB for the one-wave kernel)
     constexpr int RF = 8, RB = YLDS ? 8 : 6;
-    const int tile = blockIdx.x, lane = threadIdx.x & 63, r = threadIdx.x >> 6;
+    const int tile = WS ? tiles[blockIdx.x] : blockIdx.x, lane = threadIdx.x & 63, r = threadIdx.x >> 6;
     const int NL = G.nl, ns = G.nsteps;
     const int la = min(lane, NL - 1);                 // idle lanes shadow the last live lane's loads ...
     const bool live = lane < NL;                      // ... and store to dump locations: no divergent branch in the loops
@@ -575,16 +616,39 @@ __global__ __launch_bounds__(64 * B) void k_ilu_solve_mw(IluGeom G, const double
     double *yl = lds;                                  // slot s+1 holds y of step s (slot 0 = zeros); ring of 2 without YLDS
     double *xl = lds + (size_t)(YLDS ? ns + 1 : 2) * slotsz;      // two slots, by step parity
     double *ldump = xl + 2 * slotsz + threadIdx.x;     // where idle lanes store
-    double *gdump = ytmp + (long)gridDim.x * ns * slotsz + (long)tile * 64 * B + threadIdx.x;
+    const long dump_off = (long)G.ntiles * ns * slotsz + (long)tile * 64 * B + threadIdx.x;
+    double *gdump = ytmp + dump_off;
+    // exact select between two already-loaded doubles by a lane mask (no branch: see the 0/1-factor note in `step`)
+    auto pick = [](double a, double b, unsigned long long takeb) __attribute__((always_inline)) {
+        return __longlong_as_double((long long)((((unsigned long long)__double_as_longlong(b)) & takeb) |
+                                                (((unsigned long long)__double_as_longlong(a)) & ~takeb)));
+    };
+    const int T0 = tile % G.nt0, T1 = (tile / G.nt0) % G.nt1, T2 = tile / (G.nt0 * G.nt1);
     for (int i = threadIdx.x; i < slotsz; i += 64 * B) { yl[i] = 0.0; xl[i] = 0.0; xl[slotsz + i] = 0.0; }
     TP_LDS_BARRIER();
     int l0;
     long c;
     // ---- forward: y_c[r] = rhs_c[r] - sum_a B_a[r][:] y_(m_a) ------------------------------------------------------
-    {
+    if (phase & 1) {
         double2 v[RF][M::PFR];
         double rr[RF], rrA[RF], rrB[RF];
         bool okk[RF];
+        // WS: lower neighbours across a tile face.  Cell (l0, j, k) of this tile at step s; its -a1 neighbour when j == 0 is
+        // lane (t1-1, k) of tile T1-1 at ITS step l0 + (t1-1) + k = s + t1 - 1; -a2 when k == 0: lane (j, t2-1) of tile
+        // T2-1 at step s + t2 - 1; -a0 when l0 == 0 (step j + k): the same lane of tile T0-1 at its last cell, step
+        // (t0-1) + j + k.  (Lower neighbour tiles are never partial along the crossed axis.)  Lanes without such a neighbour
+        // load a valid dummy address and keep the LDS value (mask 0).
+        double gy1[WS ? RF : 1][B], gy2[WS ? RF : 1][B], gy0[B];
+        unsigned long long mk0[WS ? RF : 1];
+        const unsigned long long mk1 = (WS && ti.j == 0 && T1 > 0) ? ~0ull : 0ull, mk2 = (WS && ti.k == 0 && T2 > 0) ? ~0ull : 0ull;
+        const double *y1b = ytmp + ((long)(mk1 ? tile - G.nt0 : tile) * ns * B) * NL + (mk1 ? (G.t1 - 1) + G.t1 * ti.k : la);
+        const double *y2b = ytmp + ((long)(mk2 ? tile - G.nt0 * G.nt1 : tile) * ns * B) * NL + (mk2 ? ti.j + G.t1 * (G.t2 - 1) : la);
+        if (WS) {
+            const bool c0 = T0 > 0;
+            const double *y0b = ytmp + (((long)(c0 ? tile - 1 : tile) * ns + min(G.t0 - 1 + ti.j + ti.k, ns - 1)) * B) * NL + la;
+#pragma unroll
+            for (int q = 0; q < B; ++q) gy0[q] = c0 ? y0b[(long)q * NL] : 0.0;
+        }
         // Right-hand side in the grid layout: a lane's cells of consecutive steps are consecutive doubles of ITS column, but
         // the lanes of a wave sit n0 doubles apart -- one cache line per lane.  Loaded one value per step, every line is
         // fetched from L2 sixteen times (the CU's L1 does not hold the ~270 lines the three waves touch per step until the
@@ -605,6 +669,15 @@ __global__ __launch_bounds__(64 * B) void k_ilu_solve_mw(IluGeom G, const double
 #pragma unroll
             for (int p = 0; p < M::PFR; ++p) v[k][p] = ch[(long)p * NL];
             if (!BLK) rr[k] = rhs[(long)r * nt + (okk[k] ? c : park)];
+            if (WS) {
+                const int s1 = min(s + G.t1 - 1, ns - 1), s2 = min(s + G.t2 - 1, ns - 1);
+#pragma unroll
+                for (int q = 0; q < B; ++q) {
+                    gy1[WS ? k : 0][q] = y1b[((long)s1 * B + q) * NL];
+                    gy2[WS ? k : 0][q] = y2b[((long)s2 * B + q) * NL];
+                }
+                mk0[WS ? k : 0] = (T0 > 0 && s == ti.j + ti.k) ? ~0ull : 0ull;
+            }
         };
         auto step = [&](int k, int s, double rhs_k) __attribute__((always_inline)) {
             const double *yp = yl + (size_t)(YLDS ? s : (s & 1)) * slotsz;      // y of step s-1
@@ -614,7 +687,11 @@ __global__ __launch_bounds__(64 * B) void k_ilu_solve_mw(IluGeom G, const double
                 const int src = a == 0 ? la : a == 1 ? lm1 : lmt;
                 double t = 0.0;
 #pragma unroll
-                for (int q = 0; q < B; ++q) t += chunk_get<M::PFR>(v[k], a * B + q) * yp[q * NL + src];
+                for (int q = 0; q < B; ++q) {
+                    double yv = yp[q * NL + src];
+                    if (WS) yv = a == 0 ? pick(yv, gy0[q], mk0[WS ? k : 0]) : a == 1 ? pick(yv, gy1[WS ? k : 0][q], mk1) : pick(yv, gy2[WS ? k : 0][q], mk2);
+                    t += chunk_get<M::PFR>(v[k], a * B + q) * yv;
+                }
                 acc[a] = t;
             }
             // (a 0/1 factor, not a select: the compiler turns `ok ? expr : 0` into a branch around the LDS reads, and a
@@ -651,11 +728,27 @@ __global__ __launch_bounds__(64 * B) void k_ilu_solve_mw(IluGeom G, const double
         }
     }
 // ---- backward: x_c[r] = D~^-1[r][:] y_c - sum_a C_a[r][:] x_(m_a) -------------------------------------------------
-    {
+    if (phase & 2) {
         double2 v[RB][M::PBR];
         double yb[RB][YLDS ? 1 : B], aA[RB], aB[RB], xq[RB], aa[RB];
         bool okk[RB];
         long cc[RB];
+        // WS: upper neighbours across a tile face, from xtmp (the raw result of the tiles of earlier backward launches):
+        // +a1 when j == tj-1: lane (0, k) of tile T1+1 at its step l0 + k = s - j; +a2 when k == tk-1: lane (j, 0) of tile
+        // T2+1 at step s - k; +a0 when l0 == tt0-1 (step tt0-1 + j + k): the same lane of tile T0+1 at step j + k.
+        double gx1[WS ? RB : 1][B], gx2[WS ? RB : 1][B], gx0[B];
+        unsigned long long nk0[WS ? RB : 1];
+        const unsigned long long nk1 = (WS && ti.j == ti.tj - 1 && T1 < G.nt1 - 1) ? ~0ull : 0ull,
+                                 nk2 = (WS && ti.k == ti.tk - 1 && T2 < G.nt2 - 1) ? ~0ull : 0ull;
+        const double *xsrc = WS ? xtmp : ytmp;
+        const double *x1b = xsrc + ((long)(nk1 ? tile + G.nt0 : tile) * ns * B) * NL + (nk1 ? G.t1 * ti.k : la);
+        const double *x2b = xsrc + ((long)(nk2 ? tile + G.nt0 * G.nt1 : tile) * ns * B) * NL + (nk2 ? ti.j : la);
+        if (WS) {
+            const bool c0 = T0 < G.nt0 - 1;
+            const double *x0b = xsrc + (((long)(c0 ? tile + 1 : tile) * ns + min(ti.j + ti.k, ns - 1)) * B) * NL + la;
+#pragma unroll
+            for (int q = 0; q < B; ++q) gx0[q] = c0 ? x0b[(long)q * NL] : 0.0;
+        }
         const bool use = addto && r < nadd;
         const double *asrc = (use ? addto : rhs) + (long)r * nt;
         const double amask = use ? 1.0 : 0.0;
@@ -681,6 +774,15 @@ __global__ __launch_bounds__(64 * B) void k_ilu_solve_mw(IluGeom G, const double
                 for (int q = 0; q < B; ++q) yb[k][q] = ytmp[(chunk_idx(G, tile, s) * B + q) * (long)NL + la];
             }
             if (!BLK) { cc[k] = okk[k] ? c : park; aa[k] = asrc[cc[k]]; }
+            if (WS) {
+                const int s1 = max(s - ti.j, 0), s2 = max(s - ti.k, 0);
+#pragma unroll
+                for (int q = 0; q < B; ++q) {
+                    gx1[WS ? k : 0][q] = x1b[((long)s1 * B + q) * NL];
+                    gx2[WS ? k : 0][q] = x2b[((long)s2 * B + q) * NL];
+                }
+                nk0[WS ? k : 0] = (T0 < G.nt0 - 1 && s == ti.tt0 - 1 + ti.j + ti.k) ? ~0ull : 0ull;
+            }
         };
         auto step = [&](int k, int s) __attribute__((always_inline)) {
             const double *xp = xl + (size_t)((s + 1) & 1) * slotsz;             // x of step s+1
@@ -694,12 +796,17 @@ __global__ __launch_bounds__(64 * B) void k_ilu_solve_mw(IluGeom G, const double
                 const int src = a == 0 ? la : a == 1 ? lp1 : lpt;
                 double u = 0.0;
 #pragma unroll
-                for (int q = 0; q < B; ++q) u += chunk_get<M::PBR>(v[k], a * B + q) * xp[q * NL + src];
+                for (int q = 0; q < B; ++q) {
+                    double xn = xp[q * NL + src];
+                    if (WS) xn = a == 0 ? pick(xn, gx0[q], nk0[WS ? k : 0]) : a == 1 ? pick(xn, gx1[WS ? k : 0][q], nk1) : pick(xn, gx2[WS ? k : 0][q], nk2);
+                    u += chunk_get<M::PBR>(v[k], a * B + q) * xn;
+                }
                 acc[a] = u;
             }
             const double xv = (okk[k] ? 1.0 : 0.0) * (t - (acc[0] + acc[1] + acc[2]));
             double *dst = xl + (size_t)(s & 1) * slotsz + r * NL + lane;
             *(live ? dst : ldump) = xv;
+            if (WS) *(live ? xtmp + (chunk_idx(G, tile, s) * B + r) * (long)NL + lane : xtmp + dump_off) = xv;
             if (!BLK) x[(long)r * nt + cc[k]] = (okk[k] ? 1.0 : 0.0) * (amask * aa[k] + xv);
             xq[k] = xv;
             TP_LDS_BARRIER();
@@ -728,7 +835,7 @@ __global__ __launch_bounds__(64 * B) void k_ilu_solve_mw(IluGeom G, const double
         };
         // (without YLDS the forward sweep's y stores of the last steps may still be in flight: every wave re-reads values
         // written by OTHER waves of the workgroup, so drain them and make them visible first)
-        if (!YLDS) { __threadfence_block(); __syncthreads(); }
+        if (!YLDS && phase == 3) { __threadfence_block(); __syncthreads(); }
         if (BLK) blockload(aA, ns - 1);
 #pragma unroll
         for (int k = 0; k < RB; ++k)
@@ -1047,6 +1154,7 @@ static IluGeom geom_of(const tp_ctx *c) {
     G.nl = G.t1 * G.t2;
     G.ntiles = c->ilu.ntiles;
     G.rs = ilu_compact(c) ? 2 * ((G.nl + ILU_ROW_ALIGN - 1) / ILU_ROW_ALIGN * ILU_ROW_ALIGN) : 128;
+    G.ws = c->ilu.whole ? 1 : 0;
     return G;
 }
 
@@ -1079,6 +1187,7 @@ void ilu_setup(tp_ctx *c) {
     d.nt2 = (g.n2 + t2 - 1) / t2;
     d.ntiles = d.nt0 * d.nt1 * d.nt2;
     TP_REQUIRE(c->opt.ilu_levels == 0 || c->opt.ilu_levels == 1, "ilu_levels must be 0 or 1");
+    TP_REQUIRE(!(c->opt.ilu_whole && c->opt.ilu_levels), "ilu_whole (one bjacobi block per rank) is implemented for block-ILU(0)");
     d.levels = c->opt.ilu_levels;
     static const bool mw_on = !(getenv("TP_ILU_MW") && atoi(getenv("TP_ILU_MW")) == 0);
     d.mw = mw_on && d.levels == 0;
@@ -1094,6 +1203,25 @@ void ilu_setup(tp_ctx *c) {
         return;
     }
     if (c->b == 3) alloc_factor<3>(d, ilu_compact(c)); else alloc_factor<2>(d, ilu_compact(c));
+    d.whole = c->opt.ilu_whole != 0;
+    d.ndiag = 0;
+    if (d.whole) {
+        TP_REQUIRE(d.mw, "ilu_whole needs the multi-wave sweep kernel (TP_ILU_MW=0 is set)");
+        // tile-diagonals: every lower neighbour tile of a tile on diagonal d lies on diagonal d-1
+        d.ndiag = d.nt0 + d.nt1 + d.nt2 - 2;
+        std::vector<std::vector<int>> by(d.ndiag);
+        for (int t = 0; t < d.ntiles; ++t)
+            by[t % d.nt0 + (t / d.nt0) % d.nt1 + t / (d.nt0 * d.nt1)].push_back(t);
+        std::vector<int> flat;
+        d.diag_off.assign(1, 0);
+        for (auto &v : by) { flat.insert(flat.end(), v.begin(), v.end()); d.diag_off.push_back((int)flat.size()); }
+        d.diag_tiles.alloc(flat.size());
+        copy_sync(c, d.diag_tiles.p, flat.data(), sizeof(int) * flat.size(), hipMemcpyHostToDevice);
+        d.xtmp.alloc(d.ytmp.n);
+    } else {
+        d.diag_tiles.free();
+        d.xtmp.free();
+    }
 }
 
 void ilu_factor(tp_ctx *c) {
@@ -1114,10 +1242,15 @@ void ilu_factor(tp_ctx *c) {
     do {                                                                                                               \
         hipLaunchKernelGGL((k_ilu_gather<BB, CC>), dim3(c->ilu.ntiles, (IluLayout<BB>::PJ + ILU_PPT - 1) / ILU_PPT, nseg), \
                            dim3(64 * ILU_SEG), 0, c->stream, G, c->J.p, c->ilu.jt.p);                                   \
-        if (c->ilu.mw) hipLaunchKernelGGL((k_ilu_factor<BB, CC, true>), dim3(c->ilu.ntiles), dim3(64), 0, c->stream, G,   \
-                                          c->ilu.jt.p, c->ilu.fwd.p, c->ilu.bwd.p);                                      \
+        if (c->ilu.whole) {                                                                                            \
+            for (int dg = 0; dg < c->ilu.ndiag; ++dg)      /* one launch per tile-diagonal: its lower neighbours are done */ \
+                hipLaunchKernelGGL((k_ilu_factor<BB, CC, true>), dim3(c->ilu.diag_off[dg + 1] - c->ilu.diag_off[dg]), dim3(64), 0, \
+                                   c->stream, G, c->ilu.jt.p, c->ilu.fwd.p, c->ilu.bwd.p,                              \
+                                   (const int *)c->ilu.diag_tiles.p + c->ilu.diag_off[dg]);                            \
+        } else if (c->ilu.mw) hipLaunchKernelGGL((k_ilu_factor<BB, CC, true>), dim3(c->ilu.ntiles), dim3(64), 0, c->stream, G, \
+                                          c->ilu.jt.p, c->ilu.fwd.p, c->ilu.bwd.p, (const int *)nullptr);              \
         else hipLaunchKernelGGL((k_ilu_factor<BB, CC, false>), dim3(c->ilu.ntiles), dim3(64), 0, c->stream, G, c->ilu.jt.p, \
-                                c->ilu.fwd.p, c->ilu.bwd.p);                                                           \
+                                c->ilu.fwd.p, c->ilu.bwd.p, (const int *)nullptr);                                     \
     } while (0)
     if (c->b == 3) { if (cp) TP_ILU_FACTOR(3, true); else TP_ILU_FACTOR(3, false); }
     else           { if (cp) TP_ILU_FACTOR(2, true); else TP_ILU_FACTOR(2, false); }
@@ -1155,6 +1288,25 @@ void ilu_solve(tp_ctx *c, const double *r, double *x, const double *addto, int n
         const size_t slot = (size_t)c->b * G.nl * sizeof(double);
         const size_t dump = (size_t)64 * c->b * sizeof(double);            // where idle lanes store
         const size_t full = ((size_t)G.nsteps + 1 + 2) * slot + dump, ring = 4 * slot + dump;
+        if (c->ilu.whole) {
+            // one block per rank: forward over the tile-diagonals in ascending order, backward in descending order
+            static const int blk_env_w = getenv("TP_ILU_BLOCK") ? atoi(getenv("TP_ILU_BLOCK")) : -1;
+            const bool blkw = (blk_env_w >= 0 ? blk_env_w == 1 : c->g.gn2 > 1) && c->g.np >= 8;
+            const IluData &d = c->ilu;
+#define TP_ILU_WS_LAUNCH(BB, KK, DG, PH)                                                                               \
+            hipLaunchKernelGGL((k_ilu_solve_mw<BB, false, KK, true>), dim3(d.diag_off[(DG) + 1] - d.diag_off[DG]), dim3(64 * BB), \
+                               ring, c->stream, G, d.fwd.p, d.bwd.p, r, d.ytmp.p, x, addto, nadd,                      \
+                               (const int *)d.diag_tiles.p + d.diag_off[DG], PH, d.xtmp.p)
+            for (int ph = 1; ph <= 2; ++ph)
+                for (int i = 0; i < d.ndiag; ++i) {
+                    const int dg = ph == 1 ? i : d.ndiag - 1 - i;
+                    if (c->b == 3) { if (blkw) TP_ILU_WS_LAUNCH(3, true, dg, ph); else TP_ILU_WS_LAUNCH(3, false, dg, ph); }
+                    else           { if (blkw) TP_ILU_WS_LAUNCH(2, true, dg, ph); else TP_ILU_WS_LAUNCH(2, false, dg, ph); }
+                }
+#undef TP_ILU_WS_LAUNCH
+            TP_HIP(hipGetLastError());
+            return;
+        }
         static const bool ylds_mw = !(getenv("TP_ILU_YLDS") && atoi(getenv("TP_ILU_YLDS")) == 0);
         const bool yl = ylds_mw && full <= 156 * 1024;
 #define TP_ILU_MW_LAUNCH(BB, YY, KK)                                                                                    \

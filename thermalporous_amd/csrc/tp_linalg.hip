@@ -291,44 +291,25 @@ __global__ __launch_bounds__(256) void k_multi_axpy_norm(GridDev g, int nf, cons
 void orthogonalize(tp_ctx *c, int nf, const double *V, long vstride, int k, double *w, double *host_out) {
     const long nw = md_nwaves(c, nf);
     if ((long)c->gs_partial.n < (long)(k + 1) * nw) c->gs_partial.alloc((size_t)(k + 33) * nw);
-    if ((long)c->red_out.n < k + 2) c->red_out.alloc(k + 66);
-    // Several GPUs: ONE all-reduce per Krylov iteration ("one batched message of (j+2) doubles").  The k dots
-    // and ||w||^2 of the UN-orthogonalised w leave in one message; the norm of the orthogonalised vector then follows from
-    // Pythagoras, ||w - V h||^2 = ||w||^2 - sum h_i^2 (V orthonormal), with no second message.  The difference cancels when
-    // w lies almost in span(V): if less than 1e-6 of ||w||^2 is left (relative error of the difference above ~1e-10) the
-    // explicitly computed norm -- its per-rank partial sums are produced by the update kernel anyway -- is all-reduced
-    // after all.  Every rank holds the same all-reduced numbers, so every rank takes the same branch.
-    static const bool one_msg = !(getenv("TP_GS_ONE_REDUCE") && atoi(getenv("TP_GS_ONE_REDUCE")) == 0);
-    const bool fused = c->dist && one_msg;
+    if ((long)c->red_out.n < k + 1) c->red_out.alloc(k + 65);
+    // Several GPUs: TWO all-reduces per Krylov iteration (the k dots, then the norm of the orthogonalised vector), ONE host
+    // sync.  A single message per iteration was built in round 3 -- ||w - V h||^2 = ||w||^2 - sum h_i^2 with ||w||^2 riding in
+    // the dot batch -- and is unstable inside classical Gram-Schmidt: with a good preconditioner J M^-1 v_j ~ v_j, so the new
+    // direction carries 1e-4 .. 1e-8 of ||w||^2; the difference then amplifies the basis' loss of orthogonality by
+    // ||w||^2 / h_{j+1,j}^2 per iteration, the mis-normalised v_{j+1} feeds that back, and FGMRES stalls (the 2-slab case of
+    // tests/test_gpu_slabs.py: DIVERGED_ITS where two messages converge in 12 iterations).  The exact one-message form needs
+    // a lagged normalisation (two more vector passes and one wasted iteration per solve) for ~10 us of ~700: not adopted.
     TP_MD_LAUNCH(k_multi_dot, grid_for(nw * 64), dim3(256), 0, c->stream, c->g, nf, V, vstride, k, w,
-                 fused ? (const double *)w : (const double *)nullptr, c->gs_partial.p, nw);
-    hipLaunchKernelGGL(k_reduce_partials, dim3(k + (fused ? 1 : 0)), dim3(1024), 0, c->stream, c->gs_partial.p, nw, c->red_out.p);
-    allreduce_sum(c, c->red_out.p, k + (fused ? 1 : 0));
+                 (const double *)nullptr, c->gs_partial.p, nw);
+    hipLaunchKernelGGL(k_reduce_partials, dim3(k), dim3(1024), 0, c->stream, c->gs_partial.p, nw, c->red_out.p);
+    allreduce_sum(c, c->red_out.p, k);
     TP_MD_LAUNCH(k_multi_axpy_norm, grid_for(nw * 64), dim3(256), 0, c->stream, c->g, nf, V, vstride, k,
                  c->red_out.p, w, c->gs_partial.p, nw);
-    hipLaunchKernelGGL(k_reduce_partials, dim3(1), dim3(1024), 0, c->stream, c->gs_partial.p, nw, c->red_out.p + k + 1);
+    hipLaunchKernelGGL(k_reduce_partials, dim3(1), dim3(1024), 0, c->stream, c->gs_partial.p, nw, c->red_out.p + k);
     TP_HIP(hipGetLastError());
-    if (!fused) {
-        allreduce_sum(c, c->red_out.p + k + 1, 1);
-        TP_HIP(hipMemcpyAsync(host_out, c->red_out.p, sizeof(double) * k, hipMemcpyDeviceToHost, c->stream));
-        TP_HIP(hipMemcpyAsync(host_out + k, c->red_out.p + k + 1, sizeof(double), hipMemcpyDeviceToHost, c->stream));
-        TP_HIP(hipStreamSynchronize(c->stream));
-        return;
-    }
-    if (c->hostbuf.size() < (size_t)k + 2) c->hostbuf.resize(k + 66);
-    double *hb = c->hostbuf.data();
-    TP_HIP(hipMemcpyAsync(hb, c->red_out.p, sizeof(double) * (k + 1), hipMemcpyDeviceToHost, c->stream));
+    allreduce_sum(c, c->red_out.p + k, 1);
+    TP_HIP(hipMemcpyAsync(host_out, c->red_out.p, sizeof(double) * (k + 1), hipMemcpyDeviceToHost, c->stream));
     TP_HIP(hipStreamSynchronize(c->stream));
-    double sumh = 0.0;
-    for (int i = 0; i < k; ++i) { host_out[i] = hb[i]; sumh += hb[i] * hb[i]; }
-    const double ww = hb[k];
-    double rest = ww - sumh;
-    if (!(rest > 1e-6 * ww)) {          // (also taken for NaN)
-        allreduce_sum(c, c->red_out.p + k + 1, 1);
-        TP_HIP(hipMemcpyAsync(&rest, c->red_out.p + k + 1, sizeof(double), hipMemcpyDeviceToHost, c->stream));
-        TP_HIP(hipStreamSynchronize(c->stream));
-    }
-    host_out[k] = rest;
 }
 
 // ---- saturation guard (thermalmodel.py:193-229): min/max and clamp of one field over owned cells -----

@@ -45,7 +45,7 @@ static void face_strengths(tp_ctx *c, double st[3]) {
     double acc[6] = {0, 0, 0, 0, 0, 0};
     const int n[3] = {c->g.n0, c->g.n1, c->g.n2};
     for (int a = 0; a < 3; ++a) {
-        TP_HIP(hipMemcpy(h.data(), c->TK[a].p, nt * sizeof(double), hipMemcpyDeviceToHost));
+        copy_sync(c, h.data(), c->TK[a].p, nt * sizeof(double), hipMemcpyDeviceToHost);
         for (int i2 = 0; i2 < n[2]; ++i2)
             for (int i1 = 0; i1 < n[1]; ++i1)
                 for (int i0 = 0; i0 < n[0]; ++i0) {
@@ -73,7 +73,7 @@ static void refresh_pc_signature(tp_ctx *c) {
                              (uintptr_t)c->w1.p, (uintptr_t)c->w3.p, (uintptr_t)c->w4.p, (uintptr_t)c->dcoef.p, (uintptr_t)c->spbuf.p,
                              (uintptr_t)c->opt.amg_nu, (uintptr_t)c->opt.pc_kind, (uintptr_t)c->opt.decoup,
                              (uintptr_t)c->opt.amg_single, (uintptr_t)c->opt.amg_gather_cells, (uintptr_t)c->opt.schur_a11, (uintptr_t)c->opt.fs_additive, (uintptr_t)c->opt.amg_full_levels, (uintptr_t)c->opt.amg_coarse_pre, (uintptr_t)c->opt.amg_coarse_post, (uintptr_t)c->opt.amg_tail_post, (uintptr_t)c->opt.amg_mid_skip,
-                             (uintptr_t)c->ilu.ntiles, (uintptr_t)c->ilu.nsteps};
+                             (uintptr_t)c->ilu.ntiles, (uintptr_t)c->ilu.nsteps, (uintptr_t)c->ilu.whole};
     uintptr_t h = 1469598103934665603ull;
     for (uintptr_t v : sig) h = (h ^ v) * 1099511628211ull;
     if (h != c->pc_sig) { c->pc_sig = h; c->graph_epoch++; }

@@ -46,7 +46,7 @@ class tp_options(C.Structure):
                 ("ilu_t1", C.c_int32), ("ilu_t2", C.c_int32), ("ilu_t0", C.c_int32),
                 ("amg_full_levels", C.c_int32), ("amg_coarse_pre", C.c_int32), ("amg_coarse_post", C.c_int32),
                 ("amg_mid_skip", C.c_int32), ("amg_tail_post", C.c_int32), ("amg_single", C.c_int32), ("schur_a11", C.c_int32), ("amg_gather_cells", C.c_int32), ("amg_dom_tau", C.c_double),
-                ("ilu_levels", C.c_int32), ("fs_additive", C.c_int32)]
+                ("ilu_levels", C.c_int32), ("fs_additive", C.c_int32), ("ilu_whole", C.c_int32)]
 
 
 class tp_solve_info(C.Structure):
@@ -83,6 +83,8 @@ DEFAULT_OPTS = dict(
     ilu_tile=None,          # None: see default_ilu_tile (3-D: whole axis-0 lines x a balanced t1 x t2; 2-D: ~24 x 32 cells)
     ilu_levels=0,           # sub_1_sub_pc_factor_levels: 0 (block-ILU(0)) or 1 (block-ILU(1), pc_cprilu1_gmres)
     bjacobi_blocks=None,    # -sub_1_pc_bjacobi_blocks N: N blocks over the whole grid (tiles_for_blocks); overrides ilu_tile
+    ilu_whole=False,        # one bjacobi block per rank: block-ILU(0) of the whole slab (= bjacobi_blocks 1 on one GPU, PETSc's
+                            # default bjacobi on several); ilu_tile is then only the unit of the diagonal-by-diagonal sweep
 )
 
 def default_ilu_tile(n, nslabs=1, ncu=256):
@@ -118,6 +120,19 @@ def default_ilu_tile(n, nslabs=1, ncu=256):
     return best[1]
 
 
+def whole_ilu_tile(n, nslabs=1):
+    """Sweep unit (t0, t1, t2) of the whole-slab ILU(0) (``ilu_whole``): the tiles no longer cut couplings, they are swept
+    one tile-diagonal T0 + T1 + T2 = d per launch.  3-D: the balanced t1 x t2 of default_ilu_tile, and the axis-0 lines cut
+    into pieces of ~16 cells -- a diagonal of the 3-D tile grid holds up to nt0*nt1 tiles instead of nt1, and a launch
+    lasts t0 + t1 + t2 - 2 wavefront steps instead of n0 + t1 + t2 - 2 (C4: 39 launches of ~29 steps per direction instead
+    of 34 of 98).  2-D: the 24 x 32 tiles of the default."""
+    n0, n1, n2 = (int(v) for v in n)
+    t = default_ilu_tile(n, nslabs=nslabs)
+    if n2 == 1:
+        return t
+    return (-(-n0//max(1, -(-n0//16))), t[1], t[2])
+
+
 def tiles_for_blocks(n, nblocks, max_cols=64):
     """Tile (t0, t1, t2) that cuts the grid n = (n0, n1, n2) into exactly `nblocks` boxes = bjacobi blocks
     (``-sub_1_pc_bjacobi_blocks``, /root/reference/tests/test_homo_wells.py:112,125).  PETSc's blocks are contiguous row
@@ -129,6 +144,9 @@ def tiles_for_blocks(n, nblocks, max_cols=64):
     if nblocks < 1:
         raise ValueError("bjacobi_blocks must be >= 1")
     best = None
+    if nblocks == 1 and max_cols is not None and n1*n2 > max_cols:
+        raise NotImplementedError("one block over a grid of more than %d columns is not a single tile: the GPU engine realises "
+                                  "it as ilu_whole (whole-slab ILU(0) swept tile-diagonal by tile-diagonal)" % max_cols)
     for k2 in range(1, min(n2, nblocks) + 1):
         if nblocks % k2:
             continue
@@ -199,11 +217,16 @@ class HipEngine:
         self.opts = dict(DEFAULT_OPTS)
         self.opts.update(opts or {})
         if self.opts.get("bjacobi_blocks") is not None:
-            if int(nranks) > 1:
-                raise EngineError("bjacobi_blocks counts blocks over the whole grid: set ilu_tile on multi-slab runs")
-            self.opts["ilu_tile"] = tiles_for_blocks(spec["n"], self.opts["bjacobi_blocks"], max_cols=64)
+            # PETSc counts blocks over ALL ranks and needs at least one per rank: N blocks on N slabs = one per rank
+            if int(self.opts["bjacobi_blocks"]) == int(nranks):
+                self.opts["ilu_whole"] = True
+            elif int(nranks) > 1:
+                raise EngineError("bjacobi_blocks counts blocks over the whole grid: on multi-slab runs only one block per "
+                                  "rank (bjacobi_blocks = number of slabs, or ilu_whole) or an explicit ilu_tile")
+            else:
+                self.opts["ilu_tile"] = tiles_for_blocks(spec["n"], self.opts["bjacobi_blocks"], max_cols=64)
         if self.opts["ilu_tile"] is None:
-            self.opts["ilu_tile"] = default_ilu_tile(spec["n"], nslabs=int(nranks))
+            self.opts["ilu_tile"] = (whole_ilu_tile if self.opts.get("ilu_whole") else default_ilu_tile)(spec["n"], nslabs=int(nranks))
         self.nph = int(spec["nphase"])
         self.b = self.nph + 1
         n0, n1, gn2 = (int(v) for v in spec["n"])
@@ -261,7 +284,8 @@ class HipEngine:
                           o["amg_omega"], o["amg_nu"], o["amg_min_cells"], int(min(t[1], 64)), int(min(t[2], 64)),
                           0 if t[0] >= (1 << 30) else int(t[0]), int(o["amg_full_levels"]), int(o["amg_coarse_pre"]),
                           int(o["amg_coarse_post"]), int(bool(o["amg_mid_skip"])), int(o["amg_tail_post"]), int(bool(o["amg_single"])), 2 if o.get("schur_selfp") else int(bool(o["schur_a11"])),
-                          int(o["amg_gather_cells"]), float(o.get("amg_dom_tau", 0.0)), int(o.get("ilu_levels", 0)), int(bool(o.get("fs_additive", False))))
+                          int(o["amg_gather_cells"]), float(o.get("amg_dom_tau", 0.0)), int(o.get("ilu_levels", 0)), int(bool(o.get("fs_additive", False))),
+                          int(bool(o.get("ilu_whole", False))))
 
     def set_options(self, **kw):
         self.opts.update(kw)

@@ -88,7 +88,7 @@ def engine_options(solver_parameters, model_name, decoup="No", vector=False):
     o["fs_additive"] = False
     used = set()
     build_keys = ("amg_omega", "amg_nu", "amg_min_cells", "amg_full_levels", "amg_coarse_pre", "amg_coarse_post", "amg_mid_skip", "amg_tail_post", "amg_single",
-                  "amg_gather_cells", "amg_dom_tau", "ilu_tile", "ilu_levels")
+                  "amg_gather_cells", "amg_dom_tau", "ilu_tile", "ilu_levels", "ilu_whole")
     for k in build_keys:
         if k in sp:
             o[k] = sp.pop(k)
