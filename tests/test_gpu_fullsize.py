@@ -368,7 +368,7 @@ def test_c5_shaped_two_slabs_in_process():
     spec = build_spec(geo, case, params, 2)
     u0 = cases.uniform_state(spec, params.p_ref, params.T_prod, params.S_o)
     opts = dict(pc="cptr", ksp_rtol=1e-8, snes_max_it=25, amg_gather_cells=100000)
-    dts = [0.1*86400.0/1024.0, 0.2*86400.0/1024.0]
+    dts = [0.1*86400.0/8192.0, 0.2*86400.0/8192.0]       # (where the ramp of this refined case lands: ~1 s, see bench c5slab)
     h = HipEngine(spec, opts)
     h.set_state(u0)
     ref = []
