@@ -47,10 +47,13 @@ struct StencilT {
 static inline dim3 grid_for(long n, int bs = 256) { return dim3((unsigned)((n + bs - 1) / bs)); }
 
 __device__ __forceinline__ void cell_ijk(const GridDev &g, long tid, int &i0, int &i1, int &i2) {
-    i2 = (int)(tid / g.np);
-    const int rem = (int)(tid - (long)i2 * g.np);
-    i1 = rem / g.n0;
-    i0 = rem - i1 * g.n0;
+    // 32-bit unsigned divisions (every slab has fewer than 2^31 cells, tp_create): a 64-bit division is ~150 instructions on
+    // this ISA, and the few-thousand-cell levels of a V-cycle are bound by exactly that kind of per-cell index arithmetic
+    const unsigned t = (unsigned)tid, np = (unsigned)g.np, n0 = (unsigned)g.n0;
+    const unsigned q2 = t / np, rem = t - q2 * np, q1 = rem / n0;
+    i2 = (int)q2;
+    i1 = (int)q1;
+    i0 = (int)(rem - q1 * n0);
 }
 
 // Multi-GPU: along the slab axis (2) the C points are the even GLOBAL planes, so a slab that starts on an odd

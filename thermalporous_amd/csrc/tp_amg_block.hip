@@ -50,10 +50,13 @@ struct BLevelDev {
 };
 
 __device__ __forceinline__ void b_ijk(const GridDev &g, long tid, int &i0, int &i1, int &i2) {
-    i2 = (int)(tid / g.np);
-    const int rem = (int)(tid - (long)i2 * g.np);
-    i1 = rem / g.n0;
-    i0 = rem - i1 * g.n0;
+    // 32-bit unsigned divisions (every slab has fewer than 2^31 cells, tp_create): a 64-bit division is ~150 instructions on
+    // this ISA, and the few-thousand-cell levels of a V-cycle are bound by exactly that kind of per-cell index arithmetic
+    const unsigned t = (unsigned)tid, np = (unsigned)g.np, n0 = (unsigned)g.n0;
+    const unsigned q2 = t / np, rem = t - q2 * np, q1 = rem / n0;
+    i2 = (int)q2;
+    i1 = (int)q1;
+    i0 = (int)(rem - q1 * n0);
 }
 
 // ---- set-up -------------------------------------------------------------------------------------------

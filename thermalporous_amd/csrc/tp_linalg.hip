@@ -235,11 +235,15 @@ void multi_axpy(tp_ctx *c, int nf, const double *V, long vstride, int k, const d
 template <int CH>
 __global__ __launch_bounds__(256) void k_multi_axpy_norm(GridDev g, int nf, const double *__restrict__ V, long vstride,
                                                          int k, const double *__restrict__ h, double *w,
-                                                         double *__restrict__ partial, long nwaves) {
+                                                         double *__restrict__ partial, long nwaves, int rev) {
     constexpr int MD_CHUNK = CH;
-    const long wave = ((long)blockIdx.x * blockDim.x + threadIdx.x) >> 6;
+    const long wave_d = ((long)blockIdx.x * blockDim.x + threadIdx.x) >> 6;
     const int lane = threadIdx.x & 63;
-    if (wave >= nwaves) return;
+    if (wave_d >= nwaves) return;
+    // REVERSE traversal (TP_GS_REVERSE): this pass re-reads the k basis vectors the dot pass has just streamed front to back;
+    // walking back to front, the entries read first are the ones read last a moment ago -- what is still in the 256 MB
+    // Infinity Cache -- instead of the ones evicted longest ago.  Same chunks, same per-chunk sums: results unchanged.
+    const long wave = rev ? nwaves - 1 - wave_d : wave_d;
     const long nall = g.nown * nf;
     long idx[MD_CHUNK];
     bool ok[MD_CHUNK];
@@ -303,8 +307,9 @@ void orthogonalize(tp_ctx *c, int nf, const double *V, long vstride, int k, doub
                  (const double *)nullptr, c->gs_partial.p, nw);
     hipLaunchKernelGGL(k_reduce_partials, dim3(k), dim3(1024), 0, c->stream, c->gs_partial.p, nw, c->red_out.p);
     allreduce_sum(c, c->red_out.p, k);
+    static const int gs_rev = !(getenv("TP_GS_REVERSE") && atoi(getenv("TP_GS_REVERSE")) == 0);
     TP_MD_LAUNCH(k_multi_axpy_norm, grid_for(nw * 64), dim3(256), 0, c->stream, c->g, nf, V, vstride, k,
-                 c->red_out.p, w, c->gs_partial.p, nw);
+                 c->red_out.p, w, c->gs_partial.p, nw, gs_rev);
     hipLaunchKernelGGL(k_reduce_partials, dim3(1), dim3(1024), 0, c->stream, c->gs_partial.p, nw, c->red_out.p + k);
     TP_HIP(hipGetLastError());
     allreduce_sum(c, c->red_out.p + k, 1);
