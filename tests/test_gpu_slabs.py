@@ -342,3 +342,28 @@ def test_pc_apply_program_replay_on_slabs(gather):
     J, Sm = o.jacobian(want_schur=True)
     o.pc.setup(J, Sm)
     assert rel2(y1, o.pc.apply(xs)) < 1e-9
+
+
+@pytest.mark.parametrize("nranks", [2, 3])
+def test_selfp_on_slabs_equals_single_slab(nranks):
+    """pc_fieldsplit_selfp (singlephase.py:322-330) on several slabs: Sp = A11 - A10 diag(A00)^-1 A01 of a cell next to a slab
+    boundary reads its neighbour's diag(A00) and A01 row from the exchanged halo rows of the Jacobian, the exact-Sp sweep
+    exchanges x and u.  No ILU stage in this preset, so the N-slab preconditioner IS the single-slab one (to round-off)
+    and the oracle's."""
+    from oracle.engine import OracleEngine
+    spec, u0, *_ = cases.c4_spe10_3d(Nx=6, Ny=23, Nz=5, nphase=1)
+    u = cases.perturbed_state(spec, seed=5, amp=0.2)
+    xs = np.random.default_rng(11).standard_normal(u.shape)
+    opts = dict(pc="fieldsplit_cd", schur_selfp=True)
+    one, lay1, _ = run_linear_stage(spec, opts, u0, u, 3000.0, xs, 1)
+    many, layn, _ = run_linear_stage(spec, opts, u0, u, 3000.0, xs, nranks)
+    assert lay1[0] == 0 and layn[0] >= 1            # (selfp keeps the top levels on the slabs whatever amg_gather_cells says)
+    for k in ("v0", "s1", "pc"):
+        assert rel2(many[k], one[k]) < 1e-11, k
+    o = OracleEngine(spec, opts)
+    o.set_old(u0)
+    o.set_dt(3000.0)
+    o.set_state(u)
+    J, Sm = o.jacobian(want_schur=True)
+    o.pc.setup(J, Sm)
+    assert rel2(many["pc"], o.pc.apply(xs)) < 1e-9

@@ -720,7 +720,7 @@ void amg_build(tp_ctx *c, Amg *&amg, const GridDev &g0, const double strength[3]
         if (c->dist) slab_of(c, r, cur[r].first, cur[r].second);
         else cur[r] = {0, n[2]};
     }
-    const long gather_cells = c->opt.amg_gather_cells;
+    const long gather_cells = c->gather_override != -2 ? c->gather_override : (long)c->opt.amg_gather_cells;
     bool still = c->dist && gather_cells >= 0;
     int m[3] = {n[0], n[1], n[2]};
     for (size_t l = 0; l <= amg->sched.size(); ++l) {

@@ -478,8 +478,10 @@ __global__ __launch_bounds__(256) void k_selfp_build(GridDev g, Stencil A00, Ste
     const long tid = (long)blockIdx.x * blockDim.x + threadIdx.x;
     if (tid >= g.nown) return;
     const long c = g.np + tid, nt = g.ntot;
-    const int n[3] = {g.n0, g.n1, g.n2};
-    const int I[3] = {(int)(tid % g.n0), (int)((tid / g.n0) % g.n1), (int)(tid / g.np)};
+    // (axis 2 in GLOBAL plane numbers: on a slab the neighbour across the slab boundary exists -- its rows of A00 / A01 are
+    // in the halo planes of the Jacobian, exchanged before this kernel)
+    const int n[3] = {g.n0, g.n1, g.gn2};
+    const int I[3] = {(int)(tid % g.n0), (int)((tid / g.n0) % g.n1), (int)(tid / g.np) + g.off2};
     const long off[7] = {0, -1, 1, -(long)g.n0, (long)g.n0, -g.np, g.np};
     double S[7];
 #pragma unroll
@@ -558,11 +560,13 @@ void selfp_build(tp_ctx *c) {
     TP_HIP(hipGetLastError());
 }
 
-// y = x + w D^-1 (b - Sp x)
+// y = x + w D^-1 (b - Sp x)     (several GPUs: x comes in with owned cells only; u = diag(A00)^-1 A01 x is needed one plane out)
 void selfp_post(tp_ctx *c, const double *b, const double *x, double *y) {
     const GridDev &g = c->g;
     double *invd = c->spbuf.p + 7 * g.ntot, *u = c->spbuf.p + 8 * g.ntot;
+    if (c->dist) halo_exchange(c, g, const_cast<double *>(x), 1, 0);
     hipLaunchKernelGGL(k_selfp_u, xcd_grid(g.nown), dim3(256), 0, c->stream, g, c->opA00, c->opA01, x, u);
+    if (c->dist) halo_exchange(c, g, u, 1, 0);
     hipLaunchKernelGGL(k_selfp_post, xcd_grid(g.nown), dim3(256), 0, c->stream, g, c->opA10, selfp_a11(c), invd, b, x, u, y);
     TP_HIP(hipGetLastError());
 }

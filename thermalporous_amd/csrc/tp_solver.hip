@@ -133,6 +133,9 @@ void pc_setup(tp_ctx *c) {
     // bjacobi.  Grids above amg_gather_cells keep their top levels distributed over the slabs (tp_amg.hip);
     // smaller ones are replicated from the top: every rank gathers the scalar stage-1 operators.
     const GridDev gam = c->dist ? c->gfull : make_grid(c->g.n0, c->g.n1, c->g.n2, c->g.n2, 0);
+    // selfp on several GPUs works on slab vectors (its exact-Sp sweep needs the slab's own Jacobian rows): the hierarchies
+    // keep every level with >= 2 planes per rank distributed, whatever amg_gather_cells says
+    c->gather_override = (c->dist && cptr && c->opt.schur_a11 == 2) ? 0 : -2;
     if (!c->amg_p) {
         double st[3];
         face_strengths(c, st);         // coarsening schedule decided once; structure is static
@@ -156,7 +159,8 @@ void pc_setup(tp_ctx *c) {
     if (selfp) {
         // pc_fieldsplit_schur_precondition selfp (pc_fieldsplit_selfp, singlephase.py:322-330)
         TP_REQUIRE(c->opt.pc_kind == 2, "selfp is the single-phase pc_fieldsplit_selfp preset's Schur preconditioner");
-        TP_REQUIRE(!c->dist, "selfp needs the A00 diagonal and A01 rows of halo cells: one GPU only");
+        TP_REQUIRE(!c->dist || c->amg_p->dist_levels > 0, "selfp on several GPUs needs slabs of at least two planes (its Schur "
+                   "sweep works on slab vectors; the replicated global-grid stage 1 has no exact-Sp sweep)");
         if (c->spbuf.n < (size_t)10 * c->g.ntot) c->spbuf.alloc((size_t)10 * c->g.ntot);
         Sl.base = c->spbuf.p;                  // S7, filled by selfp_build on the stream of the S set-up below
         Sl.slot_stride = c->g.ntot;
@@ -189,6 +193,12 @@ void pc_setup(tp_ctx *c) {
         }
     } else if (c->dist) {
         amg_setup(c, c->amg_p, c->opA00);
+        if (selfp) {
+            // Sp of a boundary cell reads diag(A00) and the A01 row of its neighbour across the slab boundary: the Jacobian's
+            // halo rows (singlephase.py:322-330 lets PETSc form Sp from the assembled parallel matrix)
+            halo_exchange(c, c->g, c->J.p, 7 * c->b * c->b, c->g.ntot);
+            selfp_build(c);
+        }
         if (cptr) amg_setup(c, c->amg_T, Sl);
     } else {
         // one GPU: the AMG set-ups (2 x ~35 launch-latency-bound kernels) and the ILU factorisation are
