@@ -1,5 +1,6 @@
-"""Child process of tests/test_gpu_parity.py::test_env_selected_sweep_kernels: the ILU(0) sweep variants that are selected by
-environment variables read once per process (TP_ILU_MW, TP_ILU_BLOCK, TP_ILU_YLDS) against the oracle."""
+"""Child process of tests/test_gpu_parity.py::test_env_selected_sweep_kernels: the kernel variants that are selected by
+environment variables read once per process (ILU(0) sweeps: TP_ILU_MW, TP_ILU_BLOCK, TP_ILU_YLDS; LDS-tiled assembly:
+TP_ASM_LDS) against the oracle."""
 import os
 import sys
 
@@ -32,7 +33,16 @@ for builder, kw, opts in CASES:
     schur = opts["pc"] == "cptr"
     out = o.jacobian(want_schur=schur)
     J, Sm = out if schur else (out, None)
-    h.jacobian()
+    outh = h.jacobian(want_schur=schur)
+    Jh, Smh = outh if schur else (outh, None)
+    # assembly entries (the kernel variant TP_ASM_LDS selects must reproduce the default's entries)
+    assert np.abs(h.residual() - o.residual()).max() <= 1e-11*np.abs(o.residual()).max()
+    for r in range(o.b):
+        for cc in range(o.b):
+            sc = np.abs(J[:, r, cc]).max()
+            assert np.abs(Jh[:, r, cc] - J[:, r, cc]).max() <= 1e-11*sc, (builder.__name__, kw, r, cc)
+    if schur:
+        assert np.abs(Smh - Sm).max() <= 1e-11*np.abs(Sm).max()
     o.pc.setup(J, Sm)
     h.pc_setup()
     x = np.random.default_rng(11).standard_normal(u.shape)
