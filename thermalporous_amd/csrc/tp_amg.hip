@@ -865,12 +865,17 @@ static void setup_impl(tp_ctx *c, Amg *amg, const Stencil &A0) {
     AmgLevel *Lc = amg->lv.back();
     const int n = amg->ncoarse;
     const StencilT<R> opc{(R *)Lc->op.base, Lc->op.slot_stride};
-    if (n <= 64)
+    // (TP_EXP_SKIP_DENSE=1: timing experiment only -- leaves the previous inverse in place; bounds what ANY faster coarse
+    // inverse, e.g. a blocked Gauss-Jordan on v_mfma_f64_16x16x4, could gain on pc_setup: DESIGN.md 4.5)
+    static const bool skip_dense = getenv("TP_EXP_SKIP_DENSE") && atoi(getenv("TP_EXP_SKIP_DENSE")) == 1;
+    if (skip_dense && amg->dense_done) {
+    } else if (n <= 64)
         hipLaunchKernelGGL(k_amg_dense_inverse_lds<R>, dim3(1), dim3(256), 0, c->stream, Lc->g, opc, n,
                            amg->coarse_inv.p + (size_t)n * n);
     else
         hipLaunchKernelGGL(k_amg_dense_inverse<R>, dim3(1), dim3(256), 0, c->stream, Lc->g, opc, n, amg->coarse_inv.p,
                            amg->coarse_inv.p + (size_t)n * n);
+    amg->dense_done = true;
     std::vector<LevelDevT<R>> h;
     for (size_t l = 0; l < amg->lv.size(); ++l) h.push_back(dev_of<R>(amg->lv[l], (int)l, c->opt));
     amg->lvhost.assign((const char *)h.data(), (const char *)h.data() + h.size() * sizeof(LevelDevT<R>));

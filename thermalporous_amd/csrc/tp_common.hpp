@@ -165,6 +165,7 @@ struct Amg {
     hipEvent_t ev_ratio = nullptr;
     bool ratio_pending = false;
     int trunc = -1;            // level that ends the cycle with two Jacobi sweeps (-1: none)
+    bool dense_done = false;   // a coarse inverse exists (TP_EXP_SKIP_DENSE timing experiment)
     double ratio0 = 0.0;
     DBuf<char> lvdev;          // device array of level descriptors (LevelDev) for the tail kernel
     std::vector<char> lvhost;
