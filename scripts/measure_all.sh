@@ -2,6 +2,7 @@
 # Round-end measurement set on the one-GPU box; results under gpurun_out/final/ (copied to profiles/ by hand).
 #   bash scripts/measure_all.sh a   -> GPU test suite, bench (default and driver command)
 #   bash scripts/measure_all.sh b   -> other configurations, rocprofv3 kernel stats, PMC traffic passes
+#   bash scripts/measure_all.sh c   -> config 5, one slab (9 M cells: several minutes of dt ramp)
 set -e -o pipefail
 REPO=$(pwd)
 OUT=$REPO/gpurun_out/final
@@ -16,10 +17,9 @@ a)
   ;;
 b)
   for c in c1 c2 c3; do
-    python bench.py --config $c > $OUT/bench_$c.json 2> $OUT/bench_$c.err
+    python bench.py --config $c --long-steps 0 > $OUT/bench_$c.json 2> $OUT/bench_$c.err
   done
-  python bench.py --config c5slab --no-cpu-baseline > $OUT/bench_c5slab.json 2> $OUT/bench_c5slab.err
-  rocprofv3 --kernel-trace --stats --output-format csv -d $OUT/kt -- python3 bench.py --no-cpu-baseline --steps 20 --warmup 5 \
+  rocprofv3 --kernel-trace --stats --output-format csv -d $OUT/kt -- python3 bench.py --no-cpu-baseline --steps 20 --warmup 5 --long-steps 0 \
       > $OUT/bench_under_rocprof.json 2> $OUT/bench_under_rocprof.err
   find $OUT/kt -name '*kernel_trace.csv' -delete
   TP_GRAPH=0 rocprofv3 --kernel-trace --pmc FETCH_SIZE --output-format csv -d $OUT/pmc_fetch -- python3 scripts/pmc_probe.py > $OUT/pmc_fetch.log 2>&1
@@ -27,5 +27,8 @@ b)
   python3 scripts/pmc_summarize.py $OUT/pmc_fetch $OUT/pmc_write $OUT/pmc_traffic.json
   find $OUT/pmc_fetch $OUT/pmc_write -name '*kernel_trace.csv' -delete
   du -sh $OUT
+  ;;
+c)
+  python bench.py --config c5slab --no-cpu-baseline --steps 6 --warmup 2 --long-steps 0 > $OUT/bench_c5slab.json 2> $OUT/bench_c5slab.err
   ;;
 esac
