@@ -7,7 +7,7 @@ What the fixture is for: (a) the oracle is pinned against drift (tests/test_gold
 
 Per case: the perturbed state u, the old state u0, dt -> residual R, Jacobian J (7,b,b,...), [S~], and one
 Newton solve from u0 (converged state, Newton / Krylov iteration counts).
-usage: python tests/golden/make_oracle_vectors.py [r1|r2|all]     (default r2)
+usage: python tests/golden/make_oracle_vectors.py [r1|r2|r3|all]     (default r3)
 """
 import os
 import sys
@@ -38,7 +38,16 @@ CASES_R2 = {
     "c4_2ph_3d_cptramg_QI": (cases.c4_spe10_3d, dict(Nx=6, Ny=7, Nz=5, nphase=2), dict(pc="cptramg", decoup="QI", ksp_rtol=1e-8, snes_max_it=25), 86.4),
     "c4_2ph_3d_defaults": (cases.c4_spe10_3d, dict(Nx=6, Ny=9, Nz=7, nphase=2), dict(pc="cptr", ksp_rtol=1e-8, snes_max_it=25), 86.4),
 }
-ALL_CASES = {**CASES, **CASES_R2}
+# round 3 additions (oracle_vectors_r3.npz): ONE bjacobi block = ILU(0) of the whole grid (sub_1_pc_bjacobi_blocks: 1: the GPU
+# engine sweeps it tile-diagonal by tile-diagonal, the oracle has one tile), with pc_cptr and inside pc_cptr_a11; 13 x 9 = 117 > 64
+# columns in the 3-D cases: more than one wavefront
+CASES_R3 = {
+    "c4_2ph_3d_whole": (cases.c4_spe10_3d, dict(Nx=9, Ny=13, Nz=6, nphase=2), dict(pc="cptr", bjacobi_blocks=1, ksp_rtol=1e-8, snes_max_it=25), 86.4),
+    "c4_2ph_3d_a11_whole": (cases.c4_spe10_3d, dict(Nx=9, Ny=13, Nz=6, nphase=2),
+                            dict(pc="cptr", schur_a11=True, bjacobi_blocks=1, ksp_rtol=1e-8, snes_max_it=25), 86.4),
+    "c2_1ph_2d_whole": (cases.c3_spe10_2d, dict(Nx=20, Ny=70, nphase=1), dict(pc="cpr", decoup="QI", bjacobi_blocks=1, ksp_rtol=1e-8), 8640.0),
+}
+ALL_CASES = {**CASES, **CASES_R2, **CASES_R3}
 
 
 def compute(name):
@@ -64,8 +73,9 @@ def compute(name):
 
 
 if __name__ == "__main__":
-    which = sys.argv[1] if len(sys.argv) > 1 else "r2"          # "r1": regenerate the round-1 file as well
-    for tag, table, fname in (("r1", CASES, "oracle_vectors.npz"), ("r2", CASES_R2, "oracle_vectors_r2.npz")):
+    which = sys.argv[1] if len(sys.argv) > 1 else "r3"          # "r1" / "r2": regenerate the earlier rounds' files
+    for tag, table, fname in (("r1", CASES, "oracle_vectors.npz"), ("r2", CASES_R2, "oracle_vectors_r2.npz"),
+                              ("r3", CASES_R3, "oracle_vectors_r3.npz")):
         if tag != which and which != "all":
             continue
         blob = {}

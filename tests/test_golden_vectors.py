@@ -12,8 +12,8 @@ _spec = importlib.util.spec_from_file_location("make_oracle_vectors", os.path.jo
 gen = importlib.util.module_from_spec(_spec)
 _spec.loader.exec_module(gen)
 
-_files = [np.load(os.path.join(HERE, "golden", f), allow_pickle=False) for f in ("oracle_vectors.npz", "oracle_vectors_r2.npz")]
-GOLD = {k: f[k] for f in _files for k in f.files}          # (round-2 cases live in a file of their own)
+_files = [np.load(os.path.join(HERE, "golden", f), allow_pickle=False) for f in ("oracle_vectors.npz", "oracle_vectors_r2.npz", "oracle_vectors_r3.npz")]
+GOLD = {k: f[k] for f in _files for k in f.files}          # (every round's cases live in a file of their own)
 
 
 def relmax(a, b):

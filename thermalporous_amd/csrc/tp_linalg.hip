@@ -63,9 +63,9 @@ constexpr int MD_U = 4;
 template <int CH>
 __global__ __launch_bounds__(256) void k_multi_dot(GridDev g, int nf, const double *__restrict__ V, long vstride, int k,
                                                    const double *__restrict__ w, const double *__restrict__ w2,
-                                                   double *__restrict__ partial, long nwaves, int xcd) {
+                                                   double *__restrict__ partial, long nwaves) {
     constexpr int MD_CHUNK = CH;
-    const long wave = (xcd ? xcd_tid() : (long)blockIdx.x * blockDim.x + threadIdx.x) >> 6;
+    const long wave = ((long)blockIdx.x * blockDim.x + threadIdx.x) >> 6;
     const int lane = threadIdx.x & 63;
     if (wave >= nwaves) return;
     const long nall = g.nown * nf;
@@ -150,12 +150,9 @@ static int md_chunk() {
     static const int ch = (getenv("TP_MD_CHUNK") && atoi(getenv("TP_MD_CHUNK")) == 4) ? 4 : 8;
     return ch;
 }
-// TP_GS_XCD=1 (experiment): XCD-aware chunk order in the Gram-Schmidt kernels, as in the stencil kernels
-static int gs_xcd() {
-    static const int v = (getenv("TP_GS_XCD") && atoi(getenv("TP_GS_XCD")) == 1) ? 1 : 0;
-    return v;
-}
-static dim3 md_grid(long nw) { return gs_xcd() ? xcd_grid(nw * 64) : dim3((unsigned)((nw * 64 + 255) / 256)); }
+// (an XCD-aware chunk order, as in the stencil kernels, was measured in round 3: Gram-Schmidt step at k = 16 0.181-0.183 ms
+// against 0.180-0.181 ms -- pure streams have nothing to gain from it; plain block order kept)
+static dim3 md_grid(long nw) { return dim3((unsigned)((nw * 64 + 255) / 256)); }
 static long md_nwaves(const tp_ctx *c, int nf) {
     const long nall = c->g.nown * nf;
     return (nall + 64L * md_chunk() - 1) / (64L * md_chunk());
@@ -173,7 +170,7 @@ void multi_dot(tp_ctx *c, int nf, const double *V, long vstride, int k, const do
     if ((long)c->gs_partial.n < (long)nout * nw) c->gs_partial.alloc((size_t)(nout + 32) * nw);
     if ((long)c->red_out.n < nout) c->red_out.alloc(nout + 64);
     TP_MD_LAUNCH(k_multi_dot, md_grid(nw), dim3(256), 0, c->stream, c->g, nf, V, vstride, k, w, w2,
-                 c->gs_partial.p, nw, gs_xcd());
+                 c->gs_partial.p, nw);
     hipLaunchKernelGGL(k_reduce_partials, dim3(nout), dim3(1024), 0, c->stream, c->gs_partial.p, nw, c->red_out.p);
     TP_HIP(hipGetLastError());
     allreduce_sum(c, c->red_out.p, nout);
@@ -189,7 +186,7 @@ void multi_norm2sq(tp_ctx *c, int nf, int nvec, const double *const *x, double *
     if ((long)c->red_out.n < nvec) c->red_out.alloc(nvec + 64);
     for (int i = 0; i < nvec; ++i)
         TP_MD_LAUNCH(k_multi_dot, md_grid(nw), dim3(256), 0, c->stream, c->g, nf, x[i], 0L, 0, x[i], x[i],
-                     c->gs_partial.p + (long)i * nw, nw, gs_xcd());
+                     c->gs_partial.p + (long)i * nw, nw);
     hipLaunchKernelGGL(k_reduce_partials, dim3(nvec), dim3(1024), 0, c->stream, c->gs_partial.p, nw, c->red_out.p);
     TP_HIP(hipGetLastError());
     allreduce_sum(c, c->red_out.p, nvec);
@@ -241,9 +238,9 @@ void multi_axpy(tp_ctx *c, int nf, const double *V, long vstride, int k, const d
 template <int CH>
 __global__ __launch_bounds__(256) void k_multi_axpy_norm(GridDev g, int nf, const double *__restrict__ V, long vstride,
                                                          int k, const double *__restrict__ h, double *w,
-                                                         double *__restrict__ partial, long nwaves, int rev, int xcd) {
+                                                         double *__restrict__ partial, long nwaves, int rev) {
     constexpr int MD_CHUNK = CH;
-    const long wave_d = (xcd ? xcd_tid() : (long)blockIdx.x * blockDim.x + threadIdx.x) >> 6;
+    const long wave_d = ((long)blockIdx.x * blockDim.x + threadIdx.x) >> 6;
     const int lane = threadIdx.x & 63;
     if (wave_d >= nwaves) return;
     // REVERSE traversal (TP_GS_REVERSE): this pass re-reads the k basis vectors the dot pass has just streamed front to back;
@@ -310,12 +307,12 @@ void orthogonalize(tp_ctx *c, int nf, const double *V, long vstride, int k, doub
     // tests/test_gpu_slabs.py: DIVERGED_ITS where two messages converge in 12 iterations).  The exact one-message form needs
     // a lagged normalisation (two more vector passes and one wasted iteration per solve) for ~10 us of ~700: not adopted.
     TP_MD_LAUNCH(k_multi_dot, md_grid(nw), dim3(256), 0, c->stream, c->g, nf, V, vstride, k, w,
-                 (const double *)nullptr, c->gs_partial.p, nw, gs_xcd());
+                 (const double *)nullptr, c->gs_partial.p, nw);
     hipLaunchKernelGGL(k_reduce_partials, dim3(k), dim3(1024), 0, c->stream, c->gs_partial.p, nw, c->red_out.p);
     allreduce_sum(c, c->red_out.p, k);
     static const int gs_rev = !(getenv("TP_GS_REVERSE") && atoi(getenv("TP_GS_REVERSE")) == 0);
     TP_MD_LAUNCH(k_multi_axpy_norm, md_grid(nw), dim3(256), 0, c->stream, c->g, nf, V, vstride, k,
-                 c->red_out.p, w, c->gs_partial.p, nw, gs_rev, gs_xcd());
+                 c->red_out.p, w, c->gs_partial.p, nw, gs_rev);
     hipLaunchKernelGGL(k_reduce_partials, dim3(1), dim3(1024), 0, c->stream, c->gs_partial.p, nw, c->red_out.p + k);
     TP_HIP(hipGetLastError());
     allreduce_sum(c, c->red_out.p + k, 1);
