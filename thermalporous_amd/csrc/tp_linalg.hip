@@ -151,7 +151,9 @@ static int md_chunk() {
     return ch;
 }
 // (an XCD-aware chunk order, as in the stencil kernels, was measured in round 3: Gram-Schmidt step at k = 16 0.181-0.183 ms
-// against 0.180-0.181 ms -- pure streams have nothing to gain from it; plain block order kept)
+// against 0.180-0.181 ms -- pure streams have nothing to gain from it; plain block order kept.  So was a software-pipelined
+// dot kernel -- the next four vectors' 32 loads issued before the reductions of the current four: 256 VGPRs instead of 140,
+// 0.182-0.183 ms against 0.176 ms on the same box: the occupancy lost costs more than the overlap gains)
 static dim3 md_grid(long nw) { return dim3((unsigned)((nw * 64 + 255) / 256)); }
 static long md_nwaves(const tp_ctx *c, int nf) {
     const long nall = c->g.nown * nf;
