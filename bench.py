@@ -257,6 +257,8 @@ def main():
                          "long-window rate (0: off); `value` is always the K-step figure")
     ap.add_argument("--spinup-cap", type=int, default=80, help="max time steps of the untimed dt ramp")
     ap.add_argument("--grid", type=int, nargs=3, default=None, help="override Nx Ny Nz (development only)")
+    ap.add_argument("--opt", action="append", default=[], metavar="KEY=VALUE",
+                    help="engine option override for experiments (e.g. amg_full_levels=2, amg_nu=1); recorded in config.workload")
     ap.add_argument("--preset", default=None, help="solver_parameters preset instead of the configuration's own (e.g. "
                     "pc_cptramg_QI, pc_cprilu1_gmres, pc_cptr_a11): measured alternatives, never the headline")
     ap.add_argument("--save-state", default=None, help="write the state at the start of the timed region (.npz: u, dt)")
@@ -282,6 +284,12 @@ def main():
     over = {"solver_parameters": args.preset} if args.preset else {}
     model = make_model(args.config, Nxyz=Nxyz, **over)
     eng = model.engine
+    if args.opt:
+        kw = {}
+        for kv in args.opt:
+            k, v = kv.split("=", 1)
+            kw[k] = eval(v, {"__builtins__": {}}, {"True": True, "False": False, "None": None})
+        eng.set_options(**kw)
     model.start()
     # ---- spin-up: the reference's dt ramp, untimed ------------------------------------------------------
     n_spin, t_spin = spin_up(model, args.spinup_cap)
@@ -436,7 +444,8 @@ def main():
             "workload": "%s; grid %dx%dx%d (synthetic default_rng(10) field); FGMRES rtol %g; timed at dt = maxdt after an "
                         "untimed spin-up along the reference's dt ramp%s" % (desc, model.geo.Nx, model.geo.Ny, model.geo.Nz,
                                                                            eng.opts["ksp_rtol"],
-                                                                           "; PRESET %s instead of the configuration's own" % args.preset if args.preset else ""),
+                                                                           ("; PRESET %s instead of the configuration's own" % args.preset if args.preset else "") +
+                                                                           ("; OPTIONS %s" % ",".join(args.opt) if args.opt else "")),
             "fgmres_its_per_s": lits/el,
             "newton_its": nits, "fgmres_its": lits, "failed_solves": model.failed_solves - f0,
             "dt_days": [float(dts.min()), float(dts.max())],

@@ -22,31 +22,34 @@ import cases                                    # noqa: E402
 from oracle.engine import OracleEngine          # noqa: E402
 
 CASES = {
-    "c1_1ph_2d": (cases.c1_homogeneous, dict(N=8, nphase=1), dict(pc="cpr", ilu_tile=(1 << 30, 64, 1), amg_dom_tau=0.0), 86400.0),
+    "c1_1ph_2d": (cases.c1_homogeneous, dict(N=8, nphase=1), dict(pc="cpr", ilu_tile=(1 << 30, 64, 1), amg_dom_tau=0.0, amg_omega=0.8), 86400.0),
     "c3_2ph_2d": (cases.c3_spe10_2d, dict(Nx=10, Ny=12, nphase=2),
-                  dict(pc="cptr", ksp_rtol=1e-8, snes_max_it=25, ilu_tile=(1 << 30, 64, 1), amg_dom_tau=0.0), 864.0),
-    "c4_2ph_3d": (cases.c4_spe10_3d, dict(Nx=6, Ny=7, Nz=5, nphase=2), dict(pc="cptr", ksp_rtol=1e-8, snes_max_it=25, ilu_tile=(1 << 30, 8, 8), amg_dom_tau=0.0), 86.4),   # (tile and amg_dom_tau pinned: the fixtures predate the balanced tile and the relaxation-only truncation)
-    "c4_1ph_3d_fscd": (cases.c4_spe10_3d, dict(Nx=6, Ny=7, Nz=5, nphase=1), dict(pc="fieldsplit_cd", ksp_rtol=1e-8, amg_dom_tau=0.0), 864.0),
+                  dict(pc="cptr", ksp_rtol=1e-8, snes_max_it=25, ilu_tile=(1 << 30, 64, 1), amg_dom_tau=0.0, amg_omega=0.8), 864.0),
+    "c4_2ph_3d": (cases.c4_spe10_3d, dict(Nx=6, Ny=7, Nz=5, nphase=2), dict(pc="cptr", ksp_rtol=1e-8, snes_max_it=25, ilu_tile=(1 << 30, 8, 8), amg_dom_tau=0.0, amg_omega=0.8), 86.4),   # (tile and amg_dom_tau pinned: the fixtures predate the balanced tile and the relaxation-only truncation)
+    "c4_1ph_3d_fscd": (cases.c4_spe10_3d, dict(Nx=6, Ny=7, Nz=5, nphase=1), dict(pc="fieldsplit_cd", ksp_rtol=1e-8, amg_dom_tau=0.0, amg_omega=0.8), 864.0),
 }
 
 # round 2 additions, in a file of their own (oracle_vectors_r2.npz) so that the round-1 fixture stays byte-identical:
 # block-ILU(1), selfp, the system AMG of pc_cptramg, and the engines' current defaults (balanced tiles, amg_dom_tau 0.25:
 # the S~ hierarchy of the last case ends with relaxation only)
 CASES_R2 = {
-    "c4_2ph_3d_ilu1": (cases.c4_spe10_3d, dict(Nx=6, Ny=7, Nz=5, nphase=2), dict(pc="cpr", ilu_levels=1, ksp_rtol=1e-8, snes_max_it=25), 86.4),
-    "c2_1ph_2d_selfp": (cases.c3_spe10_2d, dict(Nx=10, Ny=12, nphase=1), dict(pc="fieldsplit_cd", schur_selfp=True, ksp_rtol=1e-8), 8640.0),
-    "c4_2ph_3d_cptramg_QI": (cases.c4_spe10_3d, dict(Nx=6, Ny=7, Nz=5, nphase=2), dict(pc="cptramg", decoup="QI", ksp_rtol=1e-8, snes_max_it=25), 86.4),
-    "c4_2ph_3d_defaults": (cases.c4_spe10_3d, dict(Nx=6, Ny=9, Nz=7, nphase=2), dict(pc="cptr", ksp_rtol=1e-8, snes_max_it=25), 86.4),
+    "c4_2ph_3d_ilu1": (cases.c4_spe10_3d, dict(Nx=6, Ny=7, Nz=5, nphase=2), dict(pc="cpr", ilu_levels=1, ksp_rtol=1e-8, snes_max_it=25, amg_omega=0.8), 86.4),
+    "c2_1ph_2d_selfp": (cases.c3_spe10_2d, dict(Nx=10, Ny=12, nphase=1), dict(pc="fieldsplit_cd", schur_selfp=True, ksp_rtol=1e-8, amg_omega=0.8), 8640.0),
+    "c4_2ph_3d_cptramg_QI": (cases.c4_spe10_3d, dict(Nx=6, Ny=7, Nz=5, nphase=2), dict(pc="cptramg", decoup="QI", ksp_rtol=1e-8, snes_max_it=25, amg_omega=0.8), 86.4),
+    "c4_2ph_3d_defaults": (cases.c4_spe10_3d, dict(Nx=6, Ny=9, Nz=7, nphase=2), dict(pc="cptr", ksp_rtol=1e-8, snes_max_it=25, amg_omega=0.8), 86.4),
 }
 # round 3 additions (oracle_vectors_r3.npz): ONE bjacobi block = ILU(0) of the whole grid (sub_1_pc_bjacobi_blocks: 1: the GPU
 # engine sweeps it tile-diagonal by tile-diagonal, the oracle has one tile), with pc_cptr and inside pc_cptr_a11; 13 x 9 = 117 > 64
 # columns in the 3-D cases: more than one wavefront
 CASES_R3 = {
-    "c4_2ph_3d_whole": (cases.c4_spe10_3d, dict(Nx=9, Ny=13, Nz=6, nphase=2), dict(pc="cptr", bjacobi_blocks=1, ksp_rtol=1e-8, snes_max_it=25), 86.4),
+    "c4_2ph_3d_whole": (cases.c4_spe10_3d, dict(Nx=9, Ny=13, Nz=6, nphase=2), dict(pc="cptr", bjacobi_blocks=1, ksp_rtol=1e-8, snes_max_it=25, amg_omega=0.8), 86.4),
     "c4_2ph_3d_a11_whole": (cases.c4_spe10_3d, dict(Nx=9, Ny=13, Nz=6, nphase=2),
-                            dict(pc="cptr", schur_a11=True, bjacobi_blocks=1, ksp_rtol=1e-8, snes_max_it=25), 86.4),
-    "c2_1ph_2d_whole": (cases.c3_spe10_2d, dict(Nx=20, Ny=70, nphase=1), dict(pc="cpr", decoup="QI", bjacobi_blocks=1, ksp_rtol=1e-8), 8640.0),
+                            dict(pc="cptr", schur_a11=True, bjacobi_blocks=1, ksp_rtol=1e-8, snes_max_it=25, amg_omega=0.8), 86.4),
+    "c2_1ph_2d_whole": (cases.c3_spe10_2d, dict(Nx=20, Ny=70, nphase=1), dict(pc="cpr", decoup="QI", bjacobi_blocks=1, ksp_rtol=1e-8, amg_omega=0.8), 8640.0),
+    # the engines' defaults as of round 3 (damped-Jacobi weight 0.9): nothing pinned
+    "c4_2ph_3d_defaults_r3": (cases.c4_spe10_3d, dict(Nx=6, Ny=9, Nz=7, nphase=2), dict(pc="cptr", ksp_rtol=1e-8, snes_max_it=25), 86.4),
 }
+# (amg_omega = 0.8 is pinned in every case: the fixtures predate the round-3 default of 0.9)
 ALL_CASES = {**CASES, **CASES_R2, **CASES_R3}
 
 
