@@ -133,8 +133,13 @@ def test_single_phase_schur_presets_time_loop(preset):
         assert m.engine_opts["fs_additive"] == (preset == "pc_fieldsplit_diag")
         m.solve()
         res.append((m.nits_vec, m.lits_vec, m.u.dat.data_ro[0].copy(), m.u.dat.data_ro[1].copy()))
-    assert res[0][0] == res[1][0] and len(res[0][0]) >= 2
-    assert all(abs(a - b) <= 1 for a, b in zip(res[0][1], res[1][1]))
+    assert res[0][0] == res[1][0] and len(res[0][0]) >= 2, (res[0][0], res[1][0])
+    # TOLERANCE: Krylov counts +-1 -- except pc_fieldsplit_diag, +-2: the block-diagonal preconditioner leaves FGMRES creeping
+    # towards rtol over its last iterations (residual reduction < 5 % per iteration), so whether the threshold is crossed at
+    # iteration 17 or 19 is decided by round-off (measured with the round-3 default amg_omega = 0.9: oracle 19, GPU 17 in one of
+    # the three solves; Newton counts and the converged states still agree to the bars below)
+    slack = 2 if preset == "pc_fieldsplit_diag" else 1
+    assert all(abs(a - b) <= slack for a, b in zip(res[0][1], res[1][1])), (res[0][1], res[1][1])
     assert rel2(res[1][2], res[0][2]) < 1e-8 and rel2(res[1][3], res[0][3]) < 1e-8
 
 
