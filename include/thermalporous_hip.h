@@ -221,7 +221,8 @@ int tp_amg_info(tp_ctx *ctx, int32_t which, int32_t *nlevels, double *op_complex
  * dominance ratio measured on level 0 at the last set-up */
 int tp_amg_trunc(tp_ctx *ctx, int32_t which, int32_t *level, double *ratio0);
 /* coarsening axis of every level (internal axis numbering, 2 = slab axis) and how many of the top levels are
- * distributed over the slabs (0 on one GPU and when the hierarchy is replicated, see amg_gather_cells) */
+ * distributed over the slabs (0 on one GPU and when the hierarchy is replicated, see amg_gather_cells);
+ * which: 0 pressure, 1 S~, 2 the (p,T) system hierarchy of pc_cptramg */
 int tp_amg_layout(tp_ctx *ctx, int32_t which, int32_t *dist_levels, int32_t *axes, int32_t cap, int32_t *naxes);
 
 #ifdef __cplusplus

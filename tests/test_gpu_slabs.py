@@ -367,3 +367,63 @@ def test_selfp_on_slabs_equals_single_slab(nranks):
     J, Sm = o.jacobian(want_schur=True)
     o.pc.setup(J, Sm)
     assert rel2(many["pc"], o.pc.apply(xs)) < 1e-9
+
+
+@pytest.mark.parametrize("decoup", ["No", "QI"])
+@pytest.mark.parametrize("nranks", [2, 3])
+def test_system_amg_on_slabs_equals_single_slab(decoup, nranks):
+    """pc_cptramg (twophase.py:552-566) with its 2x2-block hierarchy DISTRIBUTED over the slabs (round 3: C points = even global
+    planes, halo exchanges of the (p,T) vectors, weights / inverse diagonal blocks / slab-axis operator rows exchanged per
+    set-up, first small level gathered in place): stage 1 equals the single-slab hierarchy to round-off; the whole
+    preconditioner equals the N-slab oracle's (ILU tiles restart per slab)."""
+    from oracle.engine import OracleEngine
+    spec, u0, *_ = cases.c4_spe10_3d(Nx=8, Ny=21, Nz=7, nphase=2)
+    u = cases.perturbed_state(spec, seed=5, amp=0.2)
+    xs = np.random.default_rng(11).standard_normal(u.shape)
+    opts = dict(pc="cptramg", decoup=decoup, amg_gather_cells=0)
+
+    def stage(n):
+        from thermalporous_amd import engine as E
+        lib = E.load_library()
+        group = C.c_void_p()
+        if n > 1:
+            assert lib.tp_local_group_create(n, C.byref(group)) == 0
+        out, err = [None]*n, []
+
+        def worker(rank):
+            try:
+                h = E.HipEngine(spec, opts, rank=rank, nranks=n, local_group=group if n > 1 else None)
+                h.set_old(u0)
+                h.set_dt(3000.0)
+                h.set_state(u)
+                h.jacobian()
+                h.pc_setup()
+                h.vec_set("x", xs)
+                h.stage1_apply("x", "s1")
+                s1 = h.vec_get("s1")
+                h.vec_set("x", xs)
+                h.pc_apply("x", "pc")
+                out[rank] = (s1, h.vec_get("pc"), h.amg_layout(2))
+                h.close()
+            except Exception as e:      # noqa: BLE001
+                err.append((rank, repr(e)))
+        ts = [threading.Thread(target=worker, args=(r,)) for r in range(n)]
+        for t in ts:
+            t.start()
+        for t in ts:
+            t.join(timeout=300)
+        assert not any(t.is_alive() for t in ts), "slab worker hung"
+        if n > 1:
+            lib.tp_local_group_destroy(group)
+        assert not err, err
+        return [np.concatenate([o[k] for o in out], axis=-3) for k in range(2)] + [out[0][2]]
+    s1_one, _, lay1 = stage(1)
+    s1_n, pc_n, layn = stage(nranks)
+    assert lay1[0] == 0 and layn[0] >= 2 and 2 in layn[1][:layn[0]], (lay1, layn)     # distributed, incl. a slab-axis level
+    assert rel2(s1_n, s1_one) < 1e-11
+    o = OracleEngine(spec, dict(opts, nslabs=nranks))
+    o.set_old(u0)
+    o.set_dt(3000.0)
+    o.set_state(u)
+    o.pc.setup(o.jacobian())
+    assert rel2(pc_n, o.pc.apply(xs)) < 1e-9

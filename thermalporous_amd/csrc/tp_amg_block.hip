@@ -12,8 +12,11 @@
 //   * smoother: damped block-Jacobi with the NB x NB diagonal blocks; dense inverse (partial pivoting) on the coarsest
 //     grid; cycle shape and coarsening schedule are those of the pressure hierarchy (same options).
 // This is a "next" row of SURVEY.md 8f-3: straightforward thread-per-cell kernels (each HBM-bound: 28 operator
-// planes per sweep), no launch fusion or single-workgroup tail as in tp_amg.hip.  Multi-GPU: the hierarchy is built
-// on the gathered global grid and replicated (dist_levels = 0), as for small scalar hierarchies.
+// planes per sweep), no launch fusion or single-workgroup tail as in tp_amg.hip.  Multi-GPU (round 3): like the scalar
+// hierarchy -- levels with more than amg_gather_cells cells stay distributed over the slabs (C points = even GLOBAL planes,
+// a halo exchange in front of every kernel that reads across the slab boundary, weights / inverse diagonal blocks / -- for
+// slab-axis levels -- operator rows exchanged once per set-up), the first smaller level is gathered in place and the rest
+// of the cycle runs replicated; a grid below the threshold is replicated from the top (dist_levels = 0).
 #include "tp_common.hpp"
 #include <algorithm>
 
@@ -36,8 +39,15 @@ struct BAmg {
     std::vector<int> sched;
     DBuf<double> dense;        // [M | Minv] of the coarsest grid, (nb*ncoarse)^2 each
     int ncoarse = 0;
+    int dist_levels = 0;       // levels [0, dist_levels) are this rank's slab of the level; the rest global + replicated
+    std::vector<std::vector<std::pair<int, int>>> ranges;   // [level][rank] -> owned global planes along axis 2
     ~BAmg() { for (auto *l : lv) delete l; }
 };
+
+// slab parity / open ends along the slab axis (as in tp_amg.hip)
+__device__ __forceinline__ int b_par(const GridDev &gf, int a) { return a == 2 ? (gf.off2 & 1) : 0; }
+__device__ __forceinline__ bool b_open_lo(const GridDev &g, int a) { return a == 2 && g.nb_lo; }
+__device__ __forceinline__ bool b_open_hi(const GridDev &g, int a) { return a == 2 && g.nb_hi; }
 
 static inline dim3 grid_for(long n, int bs = 256) { return dim3((unsigned)((n + bs - 1) / bs)); }
 
@@ -103,11 +113,11 @@ __global__ void k_bamg_coarsen(BLevelDev<NB> L, GridDev gc, BStencil Ac) {
     b_ijk(gc, tid, I[0], I[1], I[2]);
     const long cc = gc.np + tid;
     int F[3] = {I[0], I[1], I[2]};
-    F[a] = 2 * I[a];
+    F[a] = 2 * I[a] + b_par(gf, a);
     const int nfa = a == 0 ? gf.n0 : (a == 1 ? gf.n1 : gf.n2);
     const long stride = a == 0 ? 1 : (a == 1 ? gf.n0 : gf.np);
     const long f = gf.np + (long)F[0] + (long)gf.n0 * F[1] + gf.np * F[2];
-    const bool hm = F[a] - 1 >= 0, hp = F[a] + 1 < nfa;
+    const bool hm = F[a] - 1 >= 0 || b_open_lo(gf, a), hp = F[a] + 1 < nfa || b_open_hi(gf, a);
     const long gm = hm ? f - stride : f, gp = hp ? f + stride : f;
     const long ntf = gf.ntot;
 #pragma unroll
@@ -274,7 +284,7 @@ __global__ __launch_bounds__(256) void k_bamg_resid(BLevelDev<NB> L, const doubl
 }
 
 template <int NB>
-__global__ __launch_bounds__(256) void k_bamg_restrict(BLevelDev<NB> Lf, GridDev gc, const double *r, double *rc) {
+__global__ __launch_bounds__(256) void k_bamg_restrict(BLevelDev<NB> Lf, GridDev gc, const double *r, double *rc, long cstride) {
     const long tid = xcd_tid();
     if (tid >= gc.nown) return;
     const GridDev &gf = Lf.g;
@@ -282,11 +292,11 @@ __global__ __launch_bounds__(256) void k_bamg_restrict(BLevelDev<NB> Lf, GridDev
     int I[3];
     b_ijk(gc, tid, I[0], I[1], I[2]);
     int F[3] = {I[0], I[1], I[2]};
-    F[a] = 2 * I[a];
+    F[a] = 2 * I[a] + b_par(gf, a);
     const int nfa = a == 0 ? gf.n0 : (a == 1 ? gf.n1 : gf.n2);
     const long stride = a == 0 ? 1 : (a == 1 ? gf.n0 : gf.np);
     const long f = gf.np + (long)F[0] + (long)gf.n0 * F[1] + gf.np * F[2];
-    const bool hm = F[a] - 1 >= 0, hp = F[a] + 1 < nfa;
+    const bool hm = F[a] - 1 >= 0 || b_open_lo(gf, a), hp = F[a] + 1 < nfa || b_open_hi(gf, a);
     const long fm = hm ? f - stride : f, fp = hp ? f + stride : f;
 #pragma unroll
     for (int q = 0; q < NB; ++q) {
@@ -294,31 +304,32 @@ __global__ __launch_bounds__(256) void k_bamg_restrict(BLevelDev<NB> Lf, GridDev
         double v = r[o + f];
         v += hp ? Lf.wm[o + fp] * r[o + fp] : 0.0;       // (order of SemiAMG.restrict: right F point first)
         v += hm ? Lf.wp[o + fm] * r[o + fm] : 0.0;
-        rc[(long)q * gc.ntot + gc.np + tid] = v;
+        rc[(long)q * cstride + gc.np + tid] = v;
     }
 }
 
 // x (+)= P ec
 template <int NB>
 __global__ __launch_bounds__(256) void k_bamg_prolong(BLevelDev<NB> Lf, GridDev gc, const double *ec, const double *xin,
-                                                      double *xout) {
+                                                      double *xout, long cstride) {
     const long tid = xcd_tid();
     if (tid >= Lf.g.nown) return;
     const GridDev &g = Lf.g;
     const int a = Lf.axis;
     int i[3];
     b_ijk(g, tid, i[0], i[1], i[2]);
-    const int Fa = i[a], Ia = Fa >> 1;
+    const int p = b_par(g, a);
+    const int Fa = i[a], Ia = (Fa - p) >> 1;          // (Fa - p may be -1: the C parent below the slab, in the halo plane)
     int I[3] = {i[0], i[1], i[2]};
     I[a] = Ia;
     const long ci = gc.np + (long)I[0] + (long)gc.n0 * I[1] + gc.np * I[2];
     const long cs = a == 0 ? 1 : (a == 1 ? gc.n0 : gc.np);
     const int nca = a == 0 ? gc.n0 : (a == 1 ? gc.n1 : gc.n2);
     const long c = g.np + tid;
-    const bool isF = Fa & 1, hasR = isF && (Ia + 1 < nca);
+    const bool isF = (Fa + p) & 1, hasR = isF && (Ia + 1 < nca || b_open_hi(gc, a));
 #pragma unroll
     for (int q = 0; q < NB; ++q) {
-        const double e0 = ec[(long)q * gc.ntot + ci], e1 = ec[(long)q * gc.ntot + (hasR ? ci + cs : ci)];
+        const double e0 = ec[(long)q * cstride + ci], e1 = ec[(long)q * cstride + (hasR ? ci + cs : ci)];
         const double v = isF ? Lf.wm[(long)q * g.ntot + c] * e0 + (hasR ? Lf.wp[(long)q * g.ntot + c] * e1 : 0.0) : e0;
         xout[(long)q * g.ntot + c] = (xin ? xin[(long)q * g.ntot + c] : 0.0) + v;
     }
@@ -351,9 +362,27 @@ void bamg_build(tp_ctx *c, BAmg *&amg, const GridDev &g0, const double strength[
     }
     int m[3] = {g0.n0, g0.n1, g0.n2};
     const int nu = std::max(1, c->opt.amg_nu);
+    // multi-GPU: the rule of tp_amg.hip:amg_build -- a level stays on the slabs while it has more than amg_gather_cells
+    // cells and every rank owns at least two of its planes
+    const int nranks = c->dist ? c->grid.nranks : 1, me = c->dist ? c->grid.rank : 0;
+    std::vector<std::pair<int, int>> cur(nranks);
+    for (int r = 0; r < nranks; ++r) {
+        if (c->dist) slab_of(c, r, cur[r].first, cur[r].second);
+        else cur[r] = {0, m[2]};
+    }
+    const long gather_cells = c->opt.amg_gather_cells;
+    bool still = c->dist && gather_cells >= 0;
     for (size_t l = 0; l <= amg->sched.size(); ++l) {
         BAmgLevel *L = new BAmgLevel();
-        L->g = make_grid(m[0], m[1], m[2], m[2], 0);
+        if (still) {
+            int minp = 1 << 30;
+            for (auto &q : cur) minp = std::min(minp, q.second - q.first);
+            still = (long)m[0] * m[1] * m[2] > gather_cells && minp >= 2 && l < amg->sched.size();
+            if (still) amg->dist_levels = (int)l + 1;
+        }
+        amg->ranges.push_back(cur);
+        L->g = still ? make_grid(m[0], m[1], cur[me].second - cur[me].first, m[2], cur[me].first)
+                     : make_grid(m[0], m[1], m[2], m[2], 0);
         const size_t nt = (size_t)L->g.ntot;
         if (l > 0) {
             L->A.alloc(7 * NB * NB * nt);
@@ -371,6 +400,8 @@ void bamg_build(tp_ctx *c, BAmg *&amg, const GridDev &g0, const double strength[
             L->axis = amg->sched[l];
             L->wm.alloc(NB * nt); L->wp.alloc(NB * nt);
             m[L->axis] = (m[L->axis] + 1) / 2;
+            if (L->axis == 2)
+                for (auto &q : cur) q = {(q.first + 1) / 2, (q.second + 1) / 2};     // even global planes survive
         }
         amg->lv.push_back(L);
     }
@@ -380,18 +411,48 @@ void bamg_build(tp_ctx *c, BAmg *&amg, const GridDev &g0, const double strength[
     amg->dense.alloc(2 * nd * nd);
 }
 
+// level l+1 as its parent level l sees it: below the last distributed level that is this rank's planes of the global
+// (replicated) arrays -- plane 0 of the view is the lower halo (tp_amg.hip:coarse_view)
+struct BCoarseView { GridDev g; long off; };
+static BCoarseView bcoarse_view(const tp_ctx *c, const BAmg *amg, int l) {
+    const BAmgLevel *Lc = amg->lv[l + 1];
+    BCoarseView v;
+    if (l + 1 < amg->dist_levels || l >= amg->dist_levels) { v.g = Lc->g; v.off = 0; return v; }
+    const auto &q = amg->ranges[l + 1][c->grid.rank];
+    v.g = make_grid(Lc->g.n0, Lc->g.n1, q.second - q.first, Lc->g.n2, q.first);
+    v.off = Lc->g.np * q.first;
+    return v;
+}
+
 void bamg_setup(tp_ctx *c, BAmg *amg, const BStencil &A0) {
     constexpr int NB = 2;
     TP_REQUIRE(amg->nb == NB, "system AMG is built for 2x2 blocks");
     amg->lv[0]->op = A0;
+    const int lg = amg->dist_levels;
     for (size_t l = 0; l < amg->lv.size(); ++l) {
         BAmgLevel *L = amg->lv[l];
         const BLevelDev<NB> Ld = bdev<NB>(L);
         hipLaunchKernelGGL(k_bamg_level<NB>, grid_for(L->g.nown), dim3(256), 0, c->stream, Ld, c->opt.amg_omega, L->wm.p,
                            L->wp.p, L->invD.p);
+        if ((int)l < lg) {
+            // distributed level: the cycle reads inverse diagonal blocks and weights of the neighbours' boundary planes,
+            // coarsening along the slab axis also their operator rows
+            const long nt = L->g.ntot;
+            halo_exchange(c, L->g, L->invD.p, NB * NB, nt);
+            if (L->axis >= 0) { halo_exchange(c, L->g, L->wm.p, NB, nt); halo_exchange(c, L->g, L->wp.p, NB, nt); }
+            if (L->axis == 2)
+                for (int sl = 0; sl < 7; ++sl)
+                    for (int q = 0; q < NB; ++q)
+                        for (int r = 0; r < NB; ++r) halo_exchange(c, L->g, L->op.at(sl, q, r), 1, 0);
+        }
         if (L->axis >= 0) {
             BAmgLevel *Lc = amg->lv[l + 1];
-            hipLaunchKernelGGL(k_bamg_coarsen<NB>, grid_for(Lc->g.nown), dim3(256), 0, c->stream, Ld, Lc->g, Lc->op);
+            const BCoarseView cv = bcoarse_view(c, amg, (int)l);
+            BStencil Ac = Lc->op;
+            Ac.base += cv.off;
+            hipLaunchKernelGGL(k_bamg_coarsen<NB>, grid_for(cv.g.nown), dim3(256), 0, c->stream, Ld, cv.g, Ac);
+            if ((int)l + 1 == lg)        // first replicated level: everybody gets everybody's rows
+                gather_ranges(c, Lc->A.p, Lc->g.np, amg->ranges[lg], 7 * NB * NB, (size_t)Lc->g.ntot * sizeof(double), sizeof(double));
         }
     }
     BAmgLevel *Lc = amg->lv.back();
@@ -408,24 +469,36 @@ void bamg_vcycle(tp_ctx *c, BAmg *amg, const double *b, double *x) {
     const dim3 bl(256);
     std::vector<double *> xs(nlev, nullptr);
     const size_t nd = (size_t)amg->ncoarse * NB;
+    const int lg = amg->dist_levels;
+    auto hx = [&](int l, const double *v) {        // halo exchange of the NB planes of a level-l vector (no-op below lg)
+        if (l < lg) halo_exchange(c, amg->lv[l]->g, const_cast<double *>(v), NB, amg->lv[l]->g.ntot);
+    };
     for (int l = 0; l < nlev - 1; ++l) {
         BAmgLevel *L = amg->lv[l], *Lc = amg->lv[l + 1];
         const BLevelDev<NB> Ld = bdev<NB>(L);
         const double *bl_ = (l == 0) ? b : L->b.p;
         const dim3 gr = xcd_grid(L->g.nown);
         const double *res = bl_;
+        const bool slab_axis = l < lg && L->axis == 2;      // the transfer itself crosses the slab boundary
         if (L->pre > 0) {
             double *cur = L->x.p, *oth = L->x2.p;
             hipLaunchKernelGGL((k_bamg_smooth<NB, true>), gr, bl, 0, c->stream, Ld, bl_, (const double *)nullptr, cur);
             for (int k = 1; k < L->pre; ++k) {
+                hx(l, cur);
                 hipLaunchKernelGGL((k_bamg_smooth<NB, false>), gr, bl, 0, c->stream, Ld, bl_, (const double *)cur, oth);
                 std::swap(cur, oth);
             }
             xs[l] = cur;
+            hx(l, cur);
             hipLaunchKernelGGL(k_bamg_resid<NB>, gr, bl, 0, c->stream, Ld, bl_, (const double *)cur, L->r.p);
             res = L->r.p;
         }
-        hipLaunchKernelGGL(k_bamg_restrict<NB>, xcd_grid(Lc->g.nown), bl, 0, c->stream, Ld, Lc->g, res, Lc->b.p);
+        if (slab_axis) hx(l, res);
+        const BCoarseView cv = bcoarse_view(c, amg, l);
+        hipLaunchKernelGGL(k_bamg_restrict<NB>, xcd_grid(cv.g.nown), bl, 0, c->stream, Ld, cv.g, res, Lc->b.p + cv.off,
+                           (long)Lc->g.ntot);
+        if (l + 1 == lg)        // restricted residual of every slab -> the replicated levels' right-hand side
+            gather_ranges(c, Lc->b.p, Lc->g.np, amg->ranges[lg], NB, (size_t)Lc->g.ntot * sizeof(double), sizeof(double));
     }
     {
         BAmgLevel *Lc = amg->lv[nlev - 1];
@@ -442,10 +515,14 @@ void bamg_vcycle(tp_ctx *c, BAmg *amg, const double *b, double *x) {
         const dim3 gr = xcd_grid(L->g.nown);
         // x <- x + P ec into a buffer that is not the final output unless no post-smoothing follows
         double *dst = (L->post == 0) ? out : (xs[l] == L->x.p ? L->x2.p : L->x.p);
-        hipLaunchKernelGGL(k_bamg_prolong<NB>, gr, bl, 0, c->stream, Ld, Lc->g, (const double *)Lc->e.p, (const double *)xs[l], dst);
+        hx(l + 1, Lc->e.p);                         // distributed coarse level: parents across the boundary
+        const BCoarseView cv = bcoarse_view(c, amg, l);
+        hipLaunchKernelGGL(k_bamg_prolong<NB>, gr, bl, 0, c->stream, Ld, cv.g, (const double *)(Lc->e.p + cv.off),
+                           (const double *)xs[l], dst, (long)Lc->g.ntot);
         double *src = dst;
         for (int k = 0; k < L->post; ++k) {
             dst = (k == L->post - 1) ? out : (src == L->x.p ? L->x2.p : L->x.p);
+            hx(l, src);
             hipLaunchKernelGGL((k_bamg_smooth<NB, false>), gr, bl, 0, c->stream, Ld, bl_, (const double *)src, dst);
             src = dst;
         }
@@ -456,5 +533,7 @@ void bamg_vcycle(tp_ctx *c, BAmg *amg, const double *b, double *x) {
 void bamg_destroy(BAmg *amg) { delete amg; }
 
 int bamg_levels(const BAmg *amg) { return (int)amg->lv.size(); }
+int bamg_dist_levels(const BAmg *amg) { return amg ? amg->dist_levels : 0; }
+const std::vector<int> &bamg_sched(const BAmg *amg) { return amg->sched; }
 
 }  // namespace tp

@@ -878,6 +878,14 @@ int tp_amg_trunc(tp_ctx *c, int32_t which, int32_t *level, double *ratio0) {
 
 int tp_amg_layout(tp_ctx *c, int32_t which, int32_t *dist_levels, int32_t *axes, int32_t cap, int32_t *naxes) {
     TP_API_BEGIN
+    if (which == 2) {       // the (p,T) system hierarchy of pc_cptramg
+        TP_REQUIRE(c->bamg, "system AMG hierarchy not built");
+        const std::vector<int> &sc = bamg_sched(c->bamg);
+        if (dist_levels) *dist_levels = bamg_dist_levels(c->bamg);
+        if (naxes) *naxes = (int)sc.size();
+        for (int i = 0; axes && i < cap && i < (int)sc.size(); ++i) axes[i] = sc[i];
+        return 0;
+    }
     Amg *amg = which == 0 ? c->amg_p : c->amg_T;
     TP_REQUIRE(amg, "AMG hierarchy not built");
     if (dist_levels) *dist_levels = amg->dist_levels;

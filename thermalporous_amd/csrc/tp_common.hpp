@@ -318,6 +318,8 @@ void bamg_setup(tp_ctx *c, BAmg *amg, const BStencil &A0);
 void bamg_vcycle(tp_ctx *c, BAmg *amg, const double *b, double *x);     // b, x: 2 planes, stride = ntot of the grid
 void bamg_destroy(BAmg *amg);
 int bamg_levels(const BAmg *amg);
+int bamg_dist_levels(const BAmg *amg);
+const std::vector<int> &bamg_sched(const BAmg *amg);
 // comm
 void halo_exchange(tp_ctx *c, const GridDev &g, double *x, int nf, long fstride);
 void halo_exchange_raw(tp_ctx *c, const GridDev &g, void *x, int nf, size_t fstride_bytes, size_t elem_bytes);

@@ -94,8 +94,9 @@ static void pc_setup_sysamg(tp_ctx *c) {
     BStencil A0;
     if (c->opt.decoup == 0) { A0.base = c->J.p; A0.ss = (long)c->b * c->b * nt; A0.rs = (long)c->b * nt; A0.cs = nt; }
     else { A0.base = c->At.p; A0.ss = 4 * nt; A0.rs = 2 * nt; A0.cs = nt; }
-    if (c->dist) {
-        // the hierarchy lives on the gathered global grid, replicated on every rank (as small scalar hierarchies do)
+    if (c->dist && bamg_dist_levels(c->bamg) == 0) {
+        // small grids: the hierarchy lives on the gathered global grid, replicated on every rank (as small scalar hierarchies
+        // do); larger ones keep their top levels on the slabs (tp_amg_block.hip) and work on the slab operator directly
         const size_t ng = (size_t)c->gfull.ntot;
         ensure_global(c, c->gAt, 28 * ng);
         ensure_global(c, c->gvec, 6 * ng);      // (sized for every pc kind: switching kinds never shrinks it)
@@ -259,7 +260,7 @@ void stage1_apply(tp_ctx *c, const double *x, double *y, bool zero_secondary) {
     }
     if (sysamg_of(c->opt)) {
         // pc_cptramg: y_pT = K(Atilde_00) r_pT, one V-cycle of the 2x2-block system AMG (r0, r1 are adjacent planes)
-        if (c->dist) {
+        if (c->dist && bamg_dist_levels(c->bamg) == 0) {
             const long ng = c->gfull.ntot;
             gather_slabs(c, r0, nt, c->gvec.p, ng, 2);
             bamg_vcycle(c, c->bamg, c->gvec.p, c->gvec.p + 2 * ng);
@@ -334,7 +335,8 @@ static void pc_apply_body(tp_ctx *c, const double *x, double *y) {
     const int npri = npri_of(c->opt);
     // (y's secondary fields are left untouched: the second stage below never reads them and overwrites them)
     stage1_apply(c, x, y, false);                 // multi-GPU, replicated stage 1: y comes back with live halo planes
-    if (c->dist && c->amg_p && c->amg_p->dist_levels > 0) halo_exchange(c, c->g, y, npri, c->g.ntot);
+    if (c->dist && ((c->amg_p && c->amg_p->dist_levels > 0) || (sysamg_of(c->opt) && bamg_dist_levels(c->bamg) > 0)))
+        halo_exchange(c, c->g, y, npri, c->g.ntot);       // (slab-distributed hierarchies return owned cells only)
     if (c->opt.pc_kind == 2) return;                          // pc_fieldsplit_cd: the Schur stage IS the preconditioner
     resid_block_cols(c, c->J.p, x, y, npri, c->w1.p);        // secondary fields of y are zero
     ilu_solve(c, c->w1.p, y, y, npri);                       // y = y + M^-1 r  (y's secondary fields are zero: not read)
