@@ -1,6 +1,6 @@
 """Child process of tests/test_gpu_parity.py::test_env_selected_sweep_kernels: the kernel variants that are selected by
-environment variables read once per process (ILU(0) sweeps: TP_ILU_MW, TP_ILU_BLOCK, TP_ILU_YLDS; LDS-tiled assembly:
-TP_ASM_LDS) against the oracle."""
+environment variables read once per process (ILU(0) sweeps: TP_ILU_MW, TP_ILU_BLOCK, TP_ILU_YLDS; ILU(1) sweeps: TP_ILU1_PACK;
+LDS-tiled assembly: TP_ASM_LDS) against the oracle."""
 import os
 import sys
 
@@ -21,7 +21,10 @@ def rel2(a, b):
 CASES = [(cases.c4_spe10_3d, dict(Nx=11, Ny=13, Nz=17, nphase=2), dict(pc="cptr", ilu_tile=(5, 4, 7))),
          (cases.c4_spe10_3d, dict(Nx=9, Ny=14, Nz=40, nphase=2), dict(pc="cptr")),                  # whole lines of 40 cells
          (cases.c4_spe10_3d, dict(Nx=7, Ny=13, Nz=9, nphase=1), dict(pc="cpr", decoup="TI")),
-         (cases.c3_spe10_2d, dict(Nx=30, Ny=41, nphase=2), dict(pc="cptr"))]
+         (cases.c3_spe10_2d, dict(Nx=30, Ny=41, nphase=2), dict(pc="cptr")),
+         # block-ILU(1): packed (default) or padded (TP_ILU1_PACK=0) stream of the sweeps, partial tiles and 2x2 blocks
+         (cases.c4_spe10_3d, dict(Nx=11, Ny=13, Nz=17, nphase=2), dict(pc="cpr", ilu_levels=1, ilu_tile=(5, 4, 7))),
+         (cases.c4_spe10_3d, dict(Nx=7, Ny=13, Nz=9, nphase=1), dict(pc="cpr", decoup="TI", ilu_levels=1, ilu_tile=(1 << 30, 8, 8)))]
 for builder, kw, opts in CASES:
     spec, u0, *_ = builder(**kw)
     o, h = OracleEngine(spec, opts), HipEngine(spec, opts)

@@ -184,6 +184,12 @@ struct IluData {
     long slots = 0;                // ntiles*nsteps*64
     bool mw = false;               // ILU(0): factor stored in the row-major layout of the multi-wave sweep (tp_ilu.hip)
     int levels = 0;                // 0: ILU(0), 1: ILU(1) (tp_options.ilu_levels; other chunk layout, see tp_ilu.hip)
+    // ILU(1): PACKED copy of the factor for the sweeps -- a (tile, step) chunk holds rows only for the lanes that have a cell
+    // at that step (the s = l0 + 2j + 4k skew leaves a third of the padded stream zero, 54-lane tiles another 16 %);
+    // pref[s] = slots before step s of a tile, ptot = slots per tile
+    DBuf<double> fwdp, bwdp;
+    DBuf<int> pref;
+    int ptot = 0;
     // tp_options.ilu_whole: one block per rank.  Tiles keep their couplings; tile-diagonal d = T0+T1+T2 is one launch:
     // tiles diag_tiles[diag_off[d] .. diag_off[d+1]) (device array); xtmp: the raw backward-sweep result of every
     // (tile, step, lane) for the tiles of later launches (x itself may already hold addto + result)

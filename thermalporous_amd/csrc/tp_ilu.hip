@@ -75,6 +75,8 @@ struct IluGeom {
     int nl;        // lanes of a wave that carry a column: t1*t2 <= 64
     int rs;        // doubles per chunk row: 2*nl when the rows are as wide as the tile (CP kernels), else 128
     int ws;        // whole-slab ILU(0) (tp_options.ilu_whole): couplings between tiles are kept
+    const int *pref;   // ILU(1) packed factor copy: slots before each step of a tile (null: padded 64-lane rows)
+    int ptot;          // slots per tile = pref[nsteps]
 };
 
 // number of double2 pairs per chunk
@@ -996,6 +998,31 @@ __global__ __launch_bounds__(64) void k_ilu1_level(IluGeom G, const double *__re
         for (int q = 0; q < B; ++q) bch[(long)(6 * BB + r * B + q) * 64] = Di[r][q];
 }
 
+// ILU(1) packed stream: does this lane's cell exist at step s in the NOMINAL tile, how many live lanes lie below it, how many
+// there are (all lanes of the wave call this together)
+__device__ __forceinline__ void packed_pos1(const IluGeom &G, const TileInfo &t, int lane, int s, bool &live, int &pos, int &cnt) {
+    const int l0 = s - 2 * t.j - 4 * t.k;
+    live = lane < G.nl && l0 >= 0 && l0 < G.t0;
+    const unsigned long long m = __ballot(live);
+    pos = live ? (int)__popcll(m & ((1ull << lane) - 1ull)) : 0;
+    cnt = G.pref[s + 1] - G.pref[s];
+}
+
+// padded factor chunks [tile][step][entry][64 lanes] -> packed [tile][step][entry][live lanes] (once per factorisation)
+template <int NE>
+__global__ __launch_bounds__(64) void k_ilu1_repack(IluGeom G, const double *__restrict__ src, double *__restrict__ dst) {
+    const int tile = blockIdx.x, s = blockIdx.y, lane = threadIdx.x;
+    const TileInfo ti = tile_info(G, tile, lane);
+    bool live;
+    int pos, cnt;
+    packed_pos1(G, ti, lane, s, live, pos, cnt);
+    if (!live) return;
+    const double *in = src + ((long)tile * G.nsteps + s) * (long)(NE * 64) + lane;
+    double *out = dst + ((long)tile * G.ptot + G.pref[s]) * (long)NE + pos;
+#pragma unroll 9
+    for (int e = 0; e < NE; ++e) out[(long)e * cnt] = in[(long)e * 64];
+}
+
 // x = addto + (L U)^-1 r for one tile per wavefront
 template <int B>
 __global__ __launch_bounds__(64) void k_ilu1_solve(IluGeom G, const double *__restrict__ fwd, const double *__restrict__ bwd,
@@ -1023,8 +1050,16 @@ __global__ __launch_bounds__(64) void k_ilu1_solve(IluGeom G, const double *__re
         auto load = [&](Buf &k, int step) {
             k.ok = tile_cell1(G, ti, step, l0, c);
             const double *ch = fwd + (chunk0 + step) * (long)(NF * 64) + lane;
+            long rl = 64;
+            if (G.pref) {                  // packed copy: rows of the live lanes only (dead lanes read slot 0: masked below)
+                bool lv;
+                int pp, cn;
+                packed_pos1(G, ti, lane, step, lv, pp, cn);
+                ch = fwd + ((long)tile * G.ptot + G.pref[step]) * (long)NF + pp;
+                rl = cn;
+            }
 #pragma unroll
-            for (int e = 0; e < NF; ++e) k.v[e] = ch[(long)e * 64];
+            for (int e = 0; e < NF; ++e) k.v[e] = ch[(long)e * rl];
             const long cs = k.ok ? c : park;
 #pragma unroll
             for (int r = 0; r < B; ++r) k.rr[r] = rhs[(long)r * nt + cs];
@@ -1086,8 +1121,16 @@ __global__ __launch_bounds__(64) void k_ilu1_solve(IluGeom G, const double *__re
             k.ok = tile_cell1(G, ti, step, l0, c);
             k.c = k.ok ? c : park;
             const double *ch = bwd + (chunk0 + step) * (long)(NB * 64) + lane;
+            long rl = 64;
+            if (G.pref) {
+                bool lv;
+                int pp, cn;
+                packed_pos1(G, ti, lane, step, lv, pp, cn);
+                ch = bwd + ((long)tile * G.ptot + G.pref[step]) * (long)NB + pp;
+                rl = cn;
+            }
 #pragma unroll
-            for (int e = 0; e < NB; ++e) k.v[e] = ch[(long)e * 64];
+            for (int e = 0; e < NB; ++e) k.v[e] = ch[(long)e * rl];
             const double *ych = ytmp + (chunk0 + step) * (long)(B * 64) + lane;
 #pragma unroll
             for (int r = 0; r < B; ++r) {
@@ -1155,6 +1198,8 @@ static IluGeom geom_of(const tp_ctx *c) {
     G.ntiles = c->ilu.ntiles;
     G.rs = ilu_compact(c) ? 2 * ((G.nl + ILU_ROW_ALIGN - 1) / ILU_ROW_ALIGN * ILU_ROW_ALIGN) : 128;
     G.ws = c->ilu.whole ? 1 : 0;
+    G.pref = nullptr;           // (set by the ILU(1) sweeps and the repack kernel only: the factorisation uses padded rows)
+    G.ptot = c->ilu.ptot;
     return G;
 }
 
@@ -1200,6 +1245,25 @@ void ilu_setup(tp_ctx *c) {
         d.bwd.alloc(chunks * 7 * bb * 64);
         d.ytmp.alloc(chunks * c->b * 64);
         d.jt.free();
+        d.whole = false;
+        static const bool pack1 = !(getenv("TP_ILU1_PACK") && atoi(getenv("TP_ILU1_PACK")) == 0);
+        d.ptot = 0;
+        if (pack1) {
+            std::vector<int> pf(d.nsteps + 1, 0);
+            for (int s = 0; s < d.nsteps; ++s) {
+                int cnt = 0;
+                for (int k = 0; k < t2; ++k)
+                    for (int j = 0; j < t1; ++j) cnt += (s - 2 * j - 4 * k >= 0 && s - 2 * j - 4 * k < t0);
+                pf[s + 1] = pf[s] + cnt;
+            }
+            d.ptot = pf[d.nsteps];
+            d.pref.alloc(pf.size());
+            copy_sync(c, d.pref.p, pf.data(), sizeof(int) * pf.size(), hipMemcpyHostToDevice);
+            d.fwdp.alloc((size_t)d.ntiles * d.ptot * 6 * bb);
+            d.bwdp.alloc((size_t)d.ntiles * d.ptot * 7 * bb);
+        } else {
+            d.fwdp.free(); d.bwdp.free(); d.pref.free();
+        }
         return;
     }
     if (c->b == 3) alloc_factor<3>(d, ilu_compact(c)); else alloc_factor<2>(d, ilu_compact(c));
@@ -1232,6 +1296,18 @@ void ilu_factor(tp_ctx *c) {
         for (int s = 0; s < G.nsteps; ++s) {
             if (c->b == 3) hipLaunchKernelGGL((k_ilu1_level<3>), dim3(c->ilu.ntiles), dim3(64), 0, c->stream, G, c->J.p, c->ilu.fwd.p, c->ilu.bwd.p, s);
             else           hipLaunchKernelGGL((k_ilu1_level<2>), dim3(c->ilu.ntiles), dim3(64), 0, c->stream, G, c->J.p, c->ilu.fwd.p, c->ilu.bwd.p, s);
+        }
+        if (c->ilu.ptot > 0) {          // the sweeps stream a packed copy
+            IluGeom Gp = G;
+            Gp.pref = c->ilu.pref.p;
+            const dim3 gr(c->ilu.ntiles, G.nsteps);
+            if (c->b == 3) {
+                hipLaunchKernelGGL((k_ilu1_repack<54>), gr, dim3(64), 0, c->stream, Gp, c->ilu.fwd.p, c->ilu.fwdp.p);
+                hipLaunchKernelGGL((k_ilu1_repack<63>), gr, dim3(64), 0, c->stream, Gp, c->ilu.bwd.p, c->ilu.bwdp.p);
+            } else {
+                hipLaunchKernelGGL((k_ilu1_repack<24>), gr, dim3(64), 0, c->stream, Gp, c->ilu.fwd.p, c->ilu.fwdp.p);
+                hipLaunchKernelGGL((k_ilu1_repack<28>), gr, dim3(64), 0, c->stream, Gp, c->ilu.bwd.p, c->ilu.bwdp.p);
+            }
         }
         TP_HIP(hipGetLastError());
         return;
@@ -1279,8 +1355,12 @@ void ilu_solve(tp_ctx *c, const double *r, double *x, const double *addto, int n
     TP_REQUIRE(c->ilu.slots > 0, "ILU not factored");
     const IluGeom G = geom_of(c);
     if (c->ilu.levels) {
-        if (c->b == 3) hipLaunchKernelGGL((k_ilu1_solve<3>), dim3(c->ilu.ntiles), dim3(64), 0, c->stream, G, c->ilu.fwd.p, c->ilu.bwd.p, r, c->ilu.ytmp.p, x, addto, nadd);
-        else           hipLaunchKernelGGL((k_ilu1_solve<2>), dim3(c->ilu.ntiles), dim3(64), 0, c->stream, G, c->ilu.fwd.p, c->ilu.bwd.p, r, c->ilu.ytmp.p, x, addto, nadd);
+        IluGeom G1 = G;
+        const bool pk = c->ilu.ptot > 0;
+        if (pk) G1.pref = c->ilu.pref.p;
+        const double *ff = pk ? c->ilu.fwdp.p : c->ilu.fwd.p, *bbk = pk ? c->ilu.bwdp.p : c->ilu.bwd.p;
+        if (c->b == 3) hipLaunchKernelGGL((k_ilu1_solve<3>), dim3(c->ilu.ntiles), dim3(64), 0, c->stream, G1, ff, bbk, r, c->ilu.ytmp.p, x, addto, nadd);
+        else           hipLaunchKernelGGL((k_ilu1_solve<2>), dim3(c->ilu.ntiles), dim3(64), 0, c->stream, G1, ff, bbk, r, c->ilu.ytmp.p, x, addto, nadd);
         TP_HIP(hipGetLastError());
         return;
     }
