@@ -1,5 +1,5 @@
 """Child process of tests/test_gpu_parity.py::test_env_selected_sweep_kernels: the kernel variants that are selected by
-environment variables read once per process (ILU(0) sweeps: TP_ILU_MW, TP_ILU_BLOCK, TP_ILU_YLDS; ILU(1) sweeps: TP_ILU1_PACK;
+environment variables read once per process (ILU(0) sweeps: TP_ILU_MW, TP_ILU_BLOCK, TP_ILU_YLDS; ILU(1) sweeps: TP_ILU1_PACK; system AMG: TP_BAMG_*;
 LDS-tiled assembly: TP_ASM_LDS) against the oracle."""
 import os
 import sys
@@ -24,7 +24,10 @@ CASES = [(cases.c4_spe10_3d, dict(Nx=11, Ny=13, Nz=17, nphase=2), dict(pc="cptr"
          (cases.c3_spe10_2d, dict(Nx=30, Ny=41, nphase=2), dict(pc="cptr")),
          # block-ILU(1): packed (default) or padded (TP_ILU1_PACK=0) stream of the sweeps, partial tiles and 2x2 blocks
          (cases.c4_spe10_3d, dict(Nx=11, Ny=13, Nz=17, nphase=2), dict(pc="cpr", ilu_levels=1, ilu_tile=(5, 4, 7))),
-         (cases.c4_spe10_3d, dict(Nx=7, Ny=13, Nz=9, nphase=1), dict(pc="cpr", decoup="TI", ilu_levels=1, ilu_tile=(1 << 30, 8, 8)))]
+         (cases.c4_spe10_3d, dict(Nx=7, Ny=13, Nz=9, nphase=1), dict(pc="cpr", decoup="TI", ilu_levels=1, ilu_tile=(1 << 30, 8, 8))),
+         # system AMG: tail kernel / fused correction / LDS dense inverse (defaults) or the per-level kernels
+         # (TP_BAMG_TAIL_CELLS=0, TP_BAMG_FUSE_BELOW=0, TP_BAMG_DENSE_LDS=0)
+         (cases.c4_spe10_3d, dict(Nx=12, Ny=20, Nz=10, nphase=2), dict(pc="cptramg", decoup="QI"))]
 for builder, kw, opts in CASES:
     spec, u0, *_ = builder(**kw)
     o, h = OracleEngine(spec, opts), HipEngine(spec, opts)

@@ -11,8 +11,10 @@
 //     interpolated with the weights of r -- the same lumped non-Galerkin 7-point formula block by block;
 //   * smoother: damped block-Jacobi with the NB x NB diagonal blocks; dense inverse (partial pivoting) on the coarsest
 //     grid; cycle shape and coarsening schedule are those of the pressure hierarchy (same options).
-// This is a "next" row of SURVEY.md 8f-3: straightforward thread-per-cell kernels (each HBM-bound: 28 operator
-// planes per sweep), no launch fusion or single-workgroup tail as in tp_amg.hip.  Multi-GPU (round 3): like the scalar
+// This is a "next" row of SURVEY.md 8f-3: thread-per-cell kernels (each HBM-bound: 28 operator planes per sweep) on the
+// big levels; like tp_amg.hip the cycle fuses the two zero-guess pre-sweeps, the coarse-grid correction with the first
+// post-sweep (mid levels), and runs every level of <= 1024 cells in ONE single-workgroup tail kernel (k_bamg_tail).
+// Multi-GPU (round 3): like the scalar
 // hierarchy -- levels with more than amg_gather_cells cells stay distributed over the slabs (C points = even GLOBAL planes,
 // a halo exchange in front of every kernel that reads across the slab boundary, weights / inverse diagonal blocks / -- for
 // slab-axis levels -- operator rows exchanged once per set-up), the first smaller level is gathered in place and the rest
@@ -40,6 +42,10 @@ struct BAmg {
     DBuf<double> dense;        // [M | Minv] of the coarsest grid, (nb*ncoarse)^2 each
     int ncoarse = 0;
     int dist_levels = 0;       // levels [0, dist_levels) are this rank's slab of the level; the rest global + replicated
+    int tail_level = 0;        // first level of the single-workgroup tail kernel (k_bamg_tail)
+    long fuse_below = 0;       // replicated levels with fewer cells fuse prolongation + first post-sweep
+    DBuf<char> lvdev;          // device array of BTailLevel descriptors
+    std::vector<char> lvhost;
     std::vector<std::vector<std::pair<int, int>>> ranges;   // [level][rank] -> owned global planes along axis 2
     ~BAmg() { for (auto *l : lv) delete l; }
 };
@@ -217,16 +223,80 @@ __global__ __launch_bounds__(256) void k_bamg_dense_inverse(BLevelDev<NB> L, int
     }
 }
 
-// e = Minv b on the coarsest grid (vectors NB planes of the level, unknowns cell-interleaved in the dense matrix)
+// The same inverse for n <= 128 unknowns, IN PLACE in LDS (n*n doubles <= 128 KB): Gauss-Jordan with partial pivoting on
+// one matrix -- the pivot column of the identity half is never stored, row swaps are undone as column swaps at the end.
+// The global-memory kernel above spends ~24 us per pivot on C4's 128 x 128 system (3.1 ms per set-up, 70 % of it).
 template <int NB>
-__global__ __launch_bounds__(256) void k_bamg_coarse_apply(GridDev g, int ncell, const double *Minv, const double *b,
-                                                           double *e) {
-    const int n = ncell * NB;
-    for (int i = threadIdx.x; i < n; i += blockDim.x) {
-        double s = 0.0;
-        for (int j = 0; j < n; ++j) s += Minv[(long)i * n + j] * b[(long)(j % NB) * g.ntot + g.np + j / NB];
-        e[(long)(i % NB) * g.ntot + g.np + i / NB] = s;
+__global__ __launch_bounds__(1024) void k_bamg_dense_inverse_lds(BLevelDev<NB> L, int ncell, double *Minv) {
+    extern __shared__ double A[];                   // n x n, row-major
+    __shared__ int s_piv[128];
+    const int n = ncell * NB, T = blockDim.x, t = threadIdx.x;
+    const GridDev &g = L.g;
+    for (int e = t; e < n * n; e += T) A[e] = 0.0;
+    __syncthreads();
+    const long off[7] = {0, -1, 1, -(long)g.n0, (long)g.n0, -g.np, g.np};
+    for (int rc = t; rc < ncell; rc += T) {
+        int i0, i1, i2;
+        b_ijk(g, rc, i0, i1, i2);
+        const long c = g.np + rc;
+        const bool has[7] = {true, i0 > 0, i0 < g.n0 - 1, i1 > 0, i1 < g.n1 - 1, i2 > 0, i2 < g.n2 - 1};
+        for (int s = 0; s < 7; ++s)
+            if (has[s])
+                for (int q = 0; q < NB; ++q)
+                    for (int r = 0; r < NB; ++r)
+                        A[(rc * NB + q) * n + (int)(rc + off[s]) * NB + r] += L.op.at(s, q, r)[c];
     }
+    __syncthreads();
+    for (int p = 0; p < n; ++p) {
+        // pivot search over rows >= p of column p: first wave, ties to the lowest row (as the global kernel)
+        if (t < 64) {
+            double best = -1.0;
+            int bi = p;
+            for (int r = p + t; r < n; r += 64) {
+                const double v = fabs(A[r * n + p]);
+                if (v > best) { best = v; bi = r; }
+            }
+#pragma unroll
+            for (int d = 32; d >= 1; d >>= 1) {
+                const double ov = __shfl_xor(best, d, 64);
+                const int oi = __shfl_xor(bi, d, 64);
+                if (ov > best || (ov == best && oi < bi)) { best = ov; bi = oi; }
+            }
+            if (t == 0) s_piv[p] = bi;
+        }
+        __syncthreads();
+        const int pr = s_piv[p];
+        if (pr != p)
+            for (int e = t; e < n; e += T) { const double v = A[p * n + e]; A[p * n + e] = A[pr * n + e]; A[pr * n + e] = v; }
+        __syncthreads();
+        const double ipiv = 1.0 / A[p * n + p];
+        __syncthreads();
+        // row p: the pivot column takes the identity's entry (1), then the row is scaled
+        for (int e = t; e < n; e += T) A[p * n + e] = (e == p ? 1.0 : A[p * n + e]) * ipiv;
+        __syncthreads();
+        // every other row i: f = A[i][p]; A[i][p] <- 0; A[i][:] -= f * A[p][:]   (one row per 16-lane group at a time)
+        const int grp = t >> 4, gl = t & 15, ng = T >> 4;
+        for (int i = grp; i < n; i += ng) {
+            if (i == p) continue;
+            const double f = A[i * n + p];
+            // all 16 lanes of the group have read f before lane (p & 15) overwrites A[i][p]: same wave, lock step
+            for (int e = gl; e < n; e += 16) {
+                const double base = (e == p) ? 0.0 : A[i * n + e];
+                A[i * n + e] = base - f * A[p * n + e];
+            }
+        }
+        __syncthreads();
+    }
+    // undo the row swaps: columns, in reverse order
+    for (int p = n - 1; p >= 0; --p) {
+        const int pr = s_piv[p];
+        if (pr != p) {
+            for (int r = t; r < n; r += T) { const double v = A[r * n + p]; A[r * n + p] = A[r * n + pr]; A[r * n + pr] = v; }
+            __syncthreads();
+        }
+    }
+    __syncthreads();
+    for (int e = t; e < n * n; e += T) Minv[e] = A[e];
 }
 
 // ---- cycle kernels -------------------------------------------------------------------------------------
@@ -335,6 +405,334 @@ __global__ __launch_bounds__(256) void k_bamg_prolong(BLevelDev<NB> Lf, GridDev 
     }
 }
 
+// ---- fused building blocks -----------------------------------------------------------------------------
+// two damped block-Jacobi sweeps from a zero guess: x1 = invD b ; out = x1 + invD (b - A x1)   (x1 of the neighbours is
+// recomputed from their b and invD: the operator is read once, no intermediate vector)
+template <int NB>
+__device__ __forceinline__ void b_pre2_cell(const BLevelDev<NB> &L, const double *__restrict__ b, long c, double (&out)[NB]) {
+    const GridDev &g = L.g;
+    const long off[7] = {0, -1, 1, -(long)g.n0, (long)g.n0, -g.np, g.np};
+    const long nt = g.ntot;
+    double r[NB], x1c[NB];
+#pragma unroll
+    for (int q = 0; q < NB; ++q) r[q] = b[(long)q * nt + c];
+#pragma unroll
+    for (int s = 0; s < 7; ++s) {
+        const long n = c + off[s];
+        double bn[NB], xv[NB];
+#pragma unroll
+        for (int k = 0; k < NB; ++k) bn[k] = b[(long)k * nt + n];
+#pragma unroll
+        for (int q = 0; q < NB; ++q) {
+            double v = 0.0;
+#pragma unroll
+            for (int k = 0; k < NB; ++k) v += L.invD[(long)(q * NB + k) * nt + n] * bn[k];
+            xv[q] = v;
+        }
+        if (s == 0) {
+#pragma unroll
+            for (int q = 0; q < NB; ++q) x1c[q] = xv[q];
+        }
+#pragma unroll
+        for (int q = 0; q < NB; ++q)
+#pragma unroll
+            for (int k = 0; k < NB; ++k) r[q] -= L.op.at(s, q, k)[c] * xv[k];
+    }
+#pragma unroll
+    for (int q = 0; q < NB; ++q) {
+        double v = x1c[q];
+#pragma unroll
+        for (int k = 0; k < NB; ++k) v += L.invD[(long)(q * NB + k) * nt + c] * r[k];
+        out[q] = v;
+    }
+}
+
+template <int NB>
+__global__ __launch_bounds__(256) void k_bamg_pre2(BLevelDev<NB> L, const double *b, double *out) {
+    const long tid = xcd_tid();
+    if (tid >= L.g.nown) return;
+    const long c = L.g.np + tid;
+    double v[NB];
+    b_pre2_cell<NB>(L, b, c, v);
+#pragma unroll
+    for (int q = 0; q < NB; ++q) out[(long)q * L.g.ntot + c] = v[q];
+}
+
+// (P ec)_q at the fine cell (F0,F1,F2) (memory-safe coordinates; replicated levels: no slab parity)
+template <int NB>
+__device__ __forceinline__ void b_prolong_val(const BLevelDev<NB> &Lf, const GridDev &gc, const double *__restrict__ ec,
+                                              long cstride, int F0, int F1, int F2, double (&v)[NB]) {
+    const GridDev &g = Lf.g;
+    const int a = Lf.axis;
+    const int p = b_par(g, a);
+    const int Fa = a == 0 ? F0 : (a == 1 ? F1 : F2);
+    const int Ia = (Fa - p) >> 1;
+    const bool isF = (Fa + p) & 1;
+    const int I0 = a == 0 ? Ia : F0, I1 = a == 1 ? Ia : F1, I2 = a == 2 ? Ia : F2;
+    const long ci = gc.np + (long)I0 + (long)gc.n0 * I1 + gc.np * I2;
+    const long cf = g.np + (long)F0 + (long)g.n0 * F1 + g.np * F2;
+    const long cs = a == 0 ? 1 : (a == 1 ? gc.n0 : gc.np);
+    const int nca = a == 0 ? gc.n0 : (a == 1 ? gc.n1 : gc.n2);
+    const bool hasR = isF && (Ia + 1 < nca || b_open_hi(gc, a));
+#pragma unroll
+    for (int q = 0; q < NB; ++q) {
+        const double wm = Lf.wm[(long)q * g.ntot + cf], wp = Lf.wp[(long)q * g.ntot + cf];
+        const double e0 = ec[(long)q * cstride + ci], e1 = ec[(long)q * cstride + (hasR ? ci + cs : ci)];
+        v[q] = isF ? wm * e0 + (hasR ? wp * e1 : 0.0) : e0;
+    }
+}
+
+// coarse-grid correction fused with the first post-sweep: x' = x + P ec ; out = x' + invD (b - A x')
+// (branch-free as tp_amg.hip:prolong_jacobi_cell: clamped neighbour coordinates, absent neighbours have zero blocks)
+template <int NB>
+__device__ __forceinline__ void b_prolong_smooth_cell(const BLevelDev<NB> &Lf, const GridDev &gc, const double *__restrict__ b,
+                                                      const double *x, const double *__restrict__ ec, long cstride, long tid,
+                                                      double (&out)[NB]) {
+    const GridDev &g = Lf.g;
+    int i0, i1, i2;
+    b_ijk(g, tid, i0, i1, i2);
+    const long c = g.np + tid, nt = g.ntot;
+    const int m0 = max(i0 - 1, 0), p0 = min(i0 + 1, g.n0 - 1);
+    const int m1 = max(i1 - 1, 0), p1 = min(i1 + 1, g.n1 - 1);
+    const int m2 = max(i2 - 1, g.nb_lo ? -1 : 0), p2 = min(i2 + 1, g.nb_hi ? g.n2 : g.n2 - 1);
+    const int N0[7] = {i0, m0, p0, i0, i0, i0, i0}, N1[7] = {i1, i1, i1, m1, p1, i1, i1}, N2[7] = {i2, i2, i2, i2, i2, m2, p2};
+    double r[NB], v0[NB];
+#pragma unroll
+    for (int q = 0; q < NB; ++q) r[q] = b[(long)q * nt + c];
+#pragma unroll
+    for (int s = 0; s < 7; ++s) {
+        double v[NB];
+        b_prolong_val<NB>(Lf, gc, ec, cstride, N0[s], N1[s], N2[s], v);
+        if (x) {
+            const long cn = g.np + (long)N0[s] + (long)g.n0 * N1[s] + g.np * N2[s];
+#pragma unroll
+            for (int k = 0; k < NB; ++k) v[k] += x[(long)k * nt + cn];
+        }
+        if (s == 0) {
+#pragma unroll
+            for (int q = 0; q < NB; ++q) v0[q] = v[q];
+        }
+#pragma unroll
+        for (int q = 0; q < NB; ++q)
+#pragma unroll
+            for (int k = 0; k < NB; ++k) r[q] -= Lf.op.at(s, q, k)[c] * v[k];
+    }
+#pragma unroll
+    for (int q = 0; q < NB; ++q) {
+        double sacc = v0[q];
+#pragma unroll
+        for (int k = 0; k < NB; ++k) sacc += Lf.invD[(long)(q * NB + k) * nt + c] * r[k];
+        out[q] = sacc;
+    }
+}
+
+template <int NB>
+__global__ __launch_bounds__(256) void k_bamg_prolong_smooth(BLevelDev<NB> Lf, GridDev gc, const double *b, const double *x,
+                                                             const double *ec, double *out, long cstride) {
+    const long tid = xcd_tid();
+    if (tid >= Lf.g.nown) return;
+    double v[NB];
+    b_prolong_smooth_cell<NB>(Lf, gc, b, x, ec, cstride, tid, v);
+#pragma unroll
+    for (int q = 0; q < NB; ++q) out[(long)q * Lf.g.ntot + Lf.g.np + tid] = v[q];
+}
+
+// (P^T r)_q at coarse cell tidc
+template <int NB>
+__device__ __forceinline__ void b_restrict_cell(const BLevelDev<NB> &Lf, const GridDev &gc, const double *__restrict__ r,
+                                                long tidc, double (&out)[NB]) {
+    const GridDev &gf = Lf.g;
+    const int a = Lf.axis;
+    int I[3];
+    b_ijk(gc, tidc, I[0], I[1], I[2]);
+    int F[3] = {I[0], I[1], I[2]};
+    F[a] = 2 * I[a] + b_par(gf, a);
+    const int nfa = a == 0 ? gf.n0 : (a == 1 ? gf.n1 : gf.n2);
+    const long stride = a == 0 ? 1 : (a == 1 ? gf.n0 : gf.np);
+    const long f = gf.np + (long)F[0] + (long)gf.n0 * F[1] + gf.np * F[2];
+    const bool hm = F[a] - 1 >= 0 || b_open_lo(gf, a), hp = F[a] + 1 < nfa || b_open_hi(gf, a);
+    const long fm = hm ? f - stride : f, fp = hp ? f + stride : f;
+#pragma unroll
+    for (int q = 0; q < NB; ++q) {
+        const long o = (long)q * gf.ntot;
+        double v = r[o + f];
+        v += hp ? Lf.wm[o + fp] * r[o + fp] : 0.0;
+        v += hm ? Lf.wp[o + fm] * r[o + fm] : 0.0;
+        out[q] = v;
+    }
+}
+
+// ---- the tail: every level of <= 1024 cells, down to the dense solve and back, in one workgroup -----------------
+// (vectors stay in global memory: a few KB per level, L2 resident; a phase boundary is a __syncthreads)
+template <int NB>
+struct BTailLevel {
+    BLevelDev<NB> d;
+    double *b, *x, *x2, *r, *e;
+    int pre, post;
+};
+
+template <int NB>
+__global__ __launch_bounds__(512) void k_bamg_tail(const BTailLevel<NB> *__restrict__ lvg, int l0, int nlev, int ncell, const double *Minv,
+                                                    const double *b_top, double *e_top) {
+    const int T = blockDim.x, t = threadIdx.x;
+    // level descriptors are read with scalar loads (uniform addresses): they live in SGPRs, not in the lanes' registers
+    const BTailLevel<NB> *__restrict__ lv = lvg;
+    // pull the read-only arrays of the tail into the L2 at once (tp_amg.hip:k_amg_tail)
+    {
+        double sink = 0.0;
+        for (int l = l0; l < nlev; ++l) {
+            const BLevelDev<NB> &L = lv[l].d;
+            for (long i = L.g.np + t; i < L.g.np + L.g.nown; i += T) {
+#pragma unroll
+                for (int s = 0; s < 7; ++s)
+#pragma unroll
+                    for (int q = 0; q < NB * NB; ++q) sink += L.op.at(s, q / NB, q % NB)[i];
+#pragma unroll
+                for (int q = 0; q < NB * NB; ++q) sink += L.invD[(long)q * L.g.ntot + i];
+                if (L.axis >= 0) {
+#pragma unroll
+                    for (int q = 0; q < NB; ++q) sink += L.wm[(long)q * L.g.ntot + i] + L.wp[(long)q * L.g.ntot + i];
+                }
+            }
+        }
+        const int n = ncell * NB;
+        for (int i = t; i < n * n; i += T) sink += Minv[i];
+        if (sink == 1.2345678e-300) e_top[0] = sink;       // never true: keeps the loads alive
+    }
+    // down-sweep (b and e of the tail's top level are the caller's; their plane stride is the level's ntot like everybody's)
+    for (int l = l0; l < nlev - 1; ++l) {
+        const BLevelDev<NB> L = lv[l].d;
+        const GridDev gc = lv[l + 1].d.g;
+        const double *b = (l == l0) ? b_top : lv[l].b;
+        const long nt = L.g.ntot;
+        double *rc = lv[l + 1].b;
+        const double *res = b;
+        if (lv[l].pre > 0) {
+            double *cur = lv[l].x, *oth = lv[l].x2;
+            for (long i = t; i < L.g.nown; i += T) {
+                const long c = L.g.np + i;
+                double v[NB];
+                if (lv[l].pre >= 2) b_pre2_cell<NB>(L, b, c, v);
+                else {
+#pragma unroll
+                    for (int q = 0; q < NB; ++q) {
+                        double sacc = 0.0;
+#pragma unroll
+                        for (int k = 0; k < NB; ++k) sacc += L.invD[(long)(q * NB + k) * nt + c] * b[(long)k * nt + c];
+                        v[q] = sacc;
+                    }
+                }
+#pragma unroll
+                for (int q = 0; q < NB; ++q) cur[(long)q * nt + c] = v[q];
+            }
+            __syncthreads();
+            for (int k = 2; k < lv[l].pre; ++k) {
+                for (long i = t; i < L.g.nown; i += T) {
+                    const long c = L.g.np + i;
+                    double r[NB];
+                    b_resid<NB>(L, b, cur, c, r);
+#pragma unroll
+                    for (int q = 0; q < NB; ++q) {
+                        double sacc = cur[(long)q * nt + c];
+#pragma unroll
+                        for (int kk = 0; kk < NB; ++kk) sacc += L.invD[(long)(q * NB + kk) * nt + c] * r[kk];
+                        oth[(long)q * nt + c] = sacc;
+                    }
+                }
+                __syncthreads();
+                double *tmp = cur; cur = oth; oth = tmp;
+            }
+            double *rr = lv[l].r;
+            for (long i = t; i < L.g.nown; i += T) {
+                const long c = L.g.np + i;
+                double v[NB];
+                b_resid<NB>(L, b, cur, c, v);
+#pragma unroll
+                for (int q = 0; q < NB; ++q) rr[(long)q * nt + c] = v[q];
+            }
+            __syncthreads();
+            res = rr;
+        }
+        for (long i = t; i < gc.nown; i += T) {
+            double v[NB];
+            b_restrict_cell<NB>(L, gc, res, i, v);
+#pragma unroll
+            for (int q = 0; q < NB; ++q) rc[(long)q * gc.ntot + gc.np + i] = v[q];
+        }
+        __syncthreads();
+    }
+    // coarsest grid: e = Minv b, 16 lanes per row
+    {
+        const BLevelDev<NB> Lc = lv[nlev - 1].d;
+        const double *b = (nlev - 1 == l0) ? b_top : lv[nlev - 1].b;
+        double *e = (nlev - 1 == l0) ? e_top : lv[nlev - 1].e;
+        const long bs = Lc.g.ntot, es = Lc.g.ntot;
+        const int n = ncell * NB;
+        const int grp = t >> 4, gl = t & 15;
+        for (int r = grp; r < n; r += T >> 4) {
+            double sacc = 0.0;
+            for (int j = gl; j < n; j += 16) sacc += Minv[(long)r * n + j] * b[(long)(j % NB) * bs + Lc.g.np + j / NB];
+            sacc += __shfl_xor(sacc, 8, 64);
+            sacc += __shfl_xor(sacc, 4, 64);
+            sacc += __shfl_xor(sacc, 2, 64);
+            sacc += __shfl_xor(sacc, 1, 64);
+            if (gl == 0) e[(long)(r % NB) * es + Lc.g.np + r / NB] = sacc;
+        }
+        __syncthreads();
+    }
+    // up-sweep
+    for (int l = nlev - 2; l >= l0; --l) {
+        const BLevelDev<NB> L = lv[l].d;
+        const GridDev gc = lv[l + 1].d.g;
+        const long nt = L.g.ntot;
+        const double *b = (l == l0) ? b_top : lv[l].b;
+        double *out = (l == l0) ? e_top : lv[l].e;
+        const long os = nt;
+        const double *ec = lv[l + 1].e;
+        const int extra = lv[l].pre >= 2 ? lv[l].pre - 2 : 0;
+        const double *src = lv[l].pre == 0 ? nullptr : ((extra % 2 == 0) ? lv[l].x : lv[l].x2);
+        if (lv[l].post == 0) {
+            for (long i = t; i < L.g.nown; i += T) {
+                int i0, i1, i2;
+                b_ijk(L.g, i, i0, i1, i2);
+                double v[NB];
+                b_prolong_val<NB>(L, gc, ec, gc.ntot, i0, i1, i2, v);
+#pragma unroll
+                for (int q = 0; q < NB; ++q) out[(long)q * os + L.g.np + i] = (src ? src[(long)q * nt + L.g.np + i] : 0.0) + v[q];
+            }
+            __syncthreads();
+            continue;
+        }
+        double *dst = (src == lv[l].x) ? lv[l].x2 : lv[l].x;
+        for (int k = 0; k < lv[l].post; ++k) {
+            const bool last = k == lv[l].post - 1;
+            double *d = last ? out : dst;
+            const long ds = last ? os : nt;
+            for (long i = t; i < L.g.nown; i += T) {
+                const long c = L.g.np + i;
+                double v[NB];
+                if (k == 0) b_prolong_smooth_cell<NB>(L, gc, b, src, ec, gc.ntot, i, v);
+                else {
+                    double r[NB];
+                    b_resid<NB>(L, b, src, c, r);
+#pragma unroll
+                    for (int q = 0; q < NB; ++q) {
+                        double sacc = src[(long)q * nt + c];
+#pragma unroll
+                        for (int kk = 0; kk < NB; ++kk) sacc += L.invD[(long)(q * NB + kk) * nt + c] * r[kk];
+                        v[q] = sacc;
+                    }
+                }
+#pragma unroll
+                for (int q = 0; q < NB; ++q) d[(long)q * ds + c] = v[q];
+            }
+            __syncthreads();
+            src = d;
+            dst = (src == lv[l].x) ? lv[l].x2 : lv[l].x;
+        }
+    }
+}
+
 // ---- host ----------------------------------------------------------------------------------------------
 template <int NB>
 static BLevelDev<NB> bdev(const BAmgLevel *L) {
@@ -405,6 +803,14 @@ void bamg_build(tp_ctx *c, BAmg *&amg, const GridDev &g0, const double strength[
         }
         amg->lv.push_back(L);
     }
+    // first level of the single-workgroup tail; replicated levels below fuse_below cells fuse prolongation + first post-sweep
+    const long tail_cells = getenv("TP_BAMG_TAIL_CELLS") ? atol(getenv("TP_BAMG_TAIL_CELLS")) : 1024;
+    amg->fuse_below = getenv("TP_BAMG_FUSE_BELOW") ? atol(getenv("TP_BAMG_FUSE_BELOW")) : 200000;
+    amg->tail_level = (int)amg->lv.size() - 1;
+    for (size_t l = (size_t)amg->dist_levels; l < amg->lv.size(); ++l)
+        if (amg->lv[l]->g.nown <= tail_cells) { amg->tail_level = (int)l; break; }
+    TP_REQUIRE((int)amg->lv.size() - amg->tail_level <= 24, "system-AMG tail has too many levels");
+    amg->lvdev.alloc(amg->lv.size() * sizeof(BTailLevel<2>));
     amg->ncoarse = (int)amg->lv.back()->g.nown;
     TP_REQUIRE(amg->ncoarse * NB <= 2048, "coarsest system-AMG grid too large for the dense solve");
     const size_t nd = (size_t)amg->ncoarse * NB;
@@ -455,17 +861,38 @@ void bamg_setup(tp_ctx *c, BAmg *amg, const BStencil &A0) {
                 gather_ranges(c, Lc->A.p, Lc->g.np, amg->ranges[lg], 7 * NB * NB, (size_t)Lc->g.ntot * sizeof(double), sizeof(double));
         }
     }
+    {
+        amg->lvhost.resize(amg->lv.size() * sizeof(BTailLevel<NB>));
+        BTailLevel<NB> *h = reinterpret_cast<BTailLevel<NB> *>(amg->lvhost.data());
+        for (size_t l = 0; l < amg->lv.size(); ++l) {
+            BAmgLevel *L = amg->lv[l];
+            memset((void *)&h[l], 0, sizeof(h[l]));
+            h[l].d = bdev<NB>(L);
+            h[l].b = L->b.p; h[l].x = L->x.p; h[l].x2 = L->x2.p; h[l].r = L->r.p; h[l].e = L->e.p;
+            h[l].pre = L->pre; h[l].post = L->post;
+        }
+        TP_HIP(hipMemcpyAsync(amg->lvdev.p, amg->lvhost.data(), amg->lvhost.size(), hipMemcpyHostToDevice, c->stream));
+    }
     BAmgLevel *Lc = amg->lv.back();
     const size_t nd = (size_t)amg->ncoarse * NB;
-    hipLaunchKernelGGL(k_bamg_dense_inverse<NB>, dim3(1), dim3(256), 0, c->stream, bdev<NB>(Lc), amg->ncoarse, amg->dense.p,
-                       amg->dense.p + nd * nd);
+    static const bool lds_inv = !(getenv("TP_BAMG_DENSE_LDS") && atoi(getenv("TP_BAMG_DENSE_LDS")) == 0);
+    if (lds_inv && nd <= 128) {
+        const size_t bytes = nd * nd * sizeof(double);
+        TP_HIP(hipFuncSetAttribute(reinterpret_cast<const void *>(&k_bamg_dense_inverse_lds<NB>),
+                                   hipFuncAttributeMaxDynamicSharedMemorySize, 128 * 128 * (int)sizeof(double)));
+        hipLaunchKernelGGL(k_bamg_dense_inverse_lds<NB>, dim3(1), dim3(1024), bytes, c->stream, bdev<NB>(Lc), amg->ncoarse,
+                           amg->dense.p + nd * nd);
+    } else {
+        hipLaunchKernelGGL(k_bamg_dense_inverse<NB>, dim3(1), dim3(256), 0, c->stream, bdev<NB>(Lc), amg->ncoarse, amg->dense.p,
+                           amg->dense.p + nd * nd);
+    }
     TP_HIP(hipGetLastError());
 }
 
 // x = V-cycle(b): b, x are NB planes with the stride of level 0 (= ntot of the grid the hierarchy was built on)
 void bamg_vcycle(tp_ctx *c, BAmg *amg, const double *b, double *x) {
     constexpr int NB = 2;
-    const int nlev = (int)amg->lv.size();
+    const int nlev = (int)amg->lv.size(), lt = amg->tail_level;
     const dim3 bl(256);
     std::vector<double *> xs(nlev, nullptr);
     const size_t nd = (size_t)amg->ncoarse * NB;
@@ -473,7 +900,8 @@ void bamg_vcycle(tp_ctx *c, BAmg *amg, const double *b, double *x) {
     auto hx = [&](int l, const double *v) {        // halo exchange of the NB planes of a level-l vector (no-op below lg)
         if (l < lg) halo_exchange(c, amg->lv[l]->g, const_cast<double *>(v), NB, amg->lv[l]->g.ntot);
     };
-    for (int l = 0; l < nlev - 1; ++l) {
+    // down-sweep over the big levels
+    for (int l = 0; l < lt; ++l) {
         BAmgLevel *L = amg->lv[l], *Lc = amg->lv[l + 1];
         const BLevelDev<NB> Ld = bdev<NB>(L);
         const double *bl_ = (l == 0) ? b : L->b.p;
@@ -482,8 +910,13 @@ void bamg_vcycle(tp_ctx *c, BAmg *amg, const double *b, double *x) {
         const bool slab_axis = l < lg && L->axis == 2;      // the transfer itself crosses the slab boundary
         if (L->pre > 0) {
             double *cur = L->x.p, *oth = L->x2.p;
-            hipLaunchKernelGGL((k_bamg_smooth<NB, true>), gr, bl, 0, c->stream, Ld, bl_, (const double *)nullptr, cur);
-            for (int k = 1; k < L->pre; ++k) {
+            if (L->pre >= 2) {
+                hx(l, bl_);                         // the fused double sweep reads invD b of the neighbours
+                hipLaunchKernelGGL(k_bamg_pre2<NB>, gr, bl, 0, c->stream, Ld, bl_, cur);
+            } else {
+                hipLaunchKernelGGL((k_bamg_smooth<NB, true>), gr, bl, 0, c->stream, Ld, bl_, (const double *)nullptr, cur);
+            }
+            for (int k = 2; k < L->pre; ++k) {
                 hx(l, cur);
                 hipLaunchKernelGGL((k_bamg_smooth<NB, false>), gr, bl, 0, c->stream, Ld, bl_, (const double *)cur, oth);
                 std::swap(cur, oth);
@@ -500,28 +933,41 @@ void bamg_vcycle(tp_ctx *c, BAmg *amg, const double *b, double *x) {
         if (l + 1 == lg)        // restricted residual of every slab -> the replicated levels' right-hand side
             gather_ranges(c, Lc->b.p, Lc->g.np, amg->ranges[lg], NB, (size_t)Lc->g.ntot * sizeof(double), sizeof(double));
     }
-    {
-        BAmgLevel *Lc = amg->lv[nlev - 1];
-        const double *bc = (nlev == 1) ? b : Lc->b.p;
-        double *ec = (nlev == 1) ? x : Lc->e.p;
-        hipLaunchKernelGGL(k_bamg_coarse_apply<NB>, dim3(1), dim3(256), 0, c->stream, Lc->g, amg->ncoarse,
-                           (const double *)(amg->dense.p + nd * nd), bc, ec);
+    {   // the tail: every level from lt down to the dense solve and back, one launch
+        BAmgLevel *Lt = amg->lv[lt];
+        const double *bt = (lt == 0) ? b : Lt->b.p;
+        double *et = (lt == 0) ? x : Lt->e.p;
+        hipLaunchKernelGGL(k_bamg_tail<NB>, dim3(1), dim3(512), 0, c->stream, (const BTailLevel<NB> *)amg->lvdev.p, lt, nlev,
+                           amg->ncoarse, (const double *)(amg->dense.p + nd * nd), bt, et);
     }
-    for (int l = nlev - 2; l >= 0; --l) {
+    // up-sweep over the big levels
+    for (int l = lt - 1; l >= 0; --l) {
         BAmgLevel *L = amg->lv[l], *Lc = amg->lv[l + 1];
         const BLevelDev<NB> Ld = bdev<NB>(L);
         const double *bl_ = (l == 0) ? b : L->b.p;
         double *out = (l == 0) ? x : L->e.p;
         const dim3 gr = xcd_grid(L->g.nown);
-        // x <- x + P ec into a buffer that is not the final output unless no post-smoothing follows
-        double *dst = (L->post == 0) ? out : (xs[l] == L->x.p ? L->x2.p : L->x.p);
         hx(l + 1, Lc->e.p);                         // distributed coarse level: parents across the boundary
         const BCoarseView cv = bcoarse_view(c, amg, l);
-        hipLaunchKernelGGL(k_bamg_prolong<NB>, gr, bl, 0, c->stream, Ld, cv.g, (const double *)(Lc->e.p + cv.off),
-                           (const double *)xs[l], dst, (long)Lc->g.ntot);
-        double *src = dst;
-        for (int k = 0; k < L->post; ++k) {
-            dst = (k == L->post - 1) ? out : (src == L->x.p ? L->x2.p : L->x.p);
+        const double *ec = Lc->e.p + cv.off;
+        double *src;
+        int k0 = 0;
+        if (L->post > 0 && L->g.nown < amg->fuse_below) {
+            // coarse-grid correction + first post-sweep in one launch (xs[l]'s halo is the one exchanged before the residual)
+            double *dst = (L->post == 1) ? out : (xs[l] == L->x.p ? L->x2.p : L->x.p);
+            hipLaunchKernelGGL(k_bamg_prolong_smooth<NB>, gr, bl, 0, c->stream, Ld, cv.g, bl_, (const double *)xs[l], ec, dst,
+                               (long)Lc->g.ntot);
+            src = dst;
+            k0 = 1;
+        } else {
+            // x <- x + P ec into a buffer that is not the final output unless no post-smoothing follows
+            double *dst = (L->post == 0) ? out : (xs[l] == L->x.p ? L->x2.p : L->x.p);
+            hipLaunchKernelGGL(k_bamg_prolong<NB>, gr, bl, 0, c->stream, Ld, cv.g, ec, (const double *)xs[l], dst,
+                               (long)Lc->g.ntot);
+            src = dst;
+        }
+        for (int k = k0; k < L->post; ++k) {
+            double *dst = (k == L->post - 1) ? out : (src == L->x.p ? L->x2.p : L->x.p);
             hx(l, src);
             hipLaunchKernelGGL((k_bamg_smooth<NB, false>), gr, bl, 0, c->stream, Ld, bl_, (const double *)src, dst);
             src = dst;
