@@ -1008,9 +1008,13 @@ __device__ __forceinline__ void packed_pos1(const IluGeom &G, const TileInfo &t,
     cnt = G.pref[s + 1] - G.pref[s];
 }
 
-// padded factor chunks [tile][step][entry][64 lanes] -> packed [tile][step][entry][live lanes] (once per factorisation)
+// padded factor chunks [tile][step][entry][64 lanes] -> packed [tile][step][entry PAIR][live lanes][2] (once per
+// factorisation).  Pairs: a sweep step then is NE/2 16-byte loads per lane instead of NE 8-byte ones -- a wave can have 63
+// vector-memory instructions in flight (vmcnt is 6 bits), so the bytes it keeps in flight double.  An odd NE is padded to the
+// next even number of entries (the pad is never written: allocations are zeroed).
 template <int NE>
 __global__ __launch_bounds__(64) void k_ilu1_repack(IluGeom G, const double *__restrict__ src, double *__restrict__ dst) {
+    constexpr int NEP = (NE + 1) & ~1;
     const int tile = blockIdx.x, s = blockIdx.y, lane = threadIdx.x;
     const TileInfo ti = tile_info(G, tile, lane);
     bool live;
@@ -1018,17 +1022,20 @@ __global__ __launch_bounds__(64) void k_ilu1_repack(IluGeom G, const double *__r
     packed_pos1(G, ti, lane, s, live, pos, cnt);
     if (!live) return;
     const double *in = src + ((long)tile * G.nsteps + s) * (long)(NE * 64) + lane;
-    double *out = dst + ((long)tile * G.ptot + G.pref[s]) * (long)NE + pos;
+    double *out = dst + ((long)tile * G.ptot + G.pref[s]) * (long)NEP + 2 * pos;
 #pragma unroll 9
-    for (int e = 0; e < NE; ++e) out[(long)e * cnt] = in[(long)e * 64];
+    for (int e = 0; e < NE; ++e) out[(long)(e >> 1) * (2 * cnt) + (e & 1)] = in[(long)e * 64];
 }
 
-// x = addto + (L U)^-1 r for one tile per wavefront
-template <int B>
+// x = addto + (L U)^-1 r for one tile per wavefront.  PF = chunks kept in registers (PF - 1 steps of loads in flight): one wave
+// per CU has nothing to hide the HBM latency with but its own prefetch depth -- with PF = 2 a step lasts one memory round trip
+// (1.5 us on C4, whatever the chunk holds)
+template <int B, int PF, bool PK>
 __global__ __launch_bounds__(64) void k_ilu1_solve(IluGeom G, const double *__restrict__ fwd, const double *__restrict__ bwd,
                                                    const double *__restrict__ rhs, double *__restrict__ ytmp, double *x,
                                                    const double *addto, int nadd) {
-    constexpr int BB = B * B, NF = 6 * BB, NB = 7 * BB;
+    constexpr int BB = B * B, NF = 6 * BB, NB = 7 * BB, NBP = (NB + 1) & ~1;
+    static_assert(NF % 2 == 0, "forward rows are loaded in pairs");
     const int tile = blockIdx.x, lane = threadIdx.x;
     const long nt = G.g.ntot;
     const TileInfo ti = tile_info(G, tile, lane);
@@ -1046,20 +1053,25 @@ __global__ __launch_bounds__(64) void k_ilu1_solve(IluGeom G, const double *__re
 #pragma unroll
             for (int r = 0; r < B; ++r) yh[d][r] = 0.0;
         struct Buf { double v[NF], rr[B]; bool ok; };
-        Buf buf[2];
+        Buf buf[3];
         auto load = [&](Buf &k, int step) {
             k.ok = tile_cell1(G, ti, step, l0, c);
-            const double *ch = fwd + (chunk0 + step) * (long)(NF * 64) + lane;
-            long rl = 64;
-            if (G.pref) {                  // packed copy: rows of the live lanes only (dead lanes read slot 0: masked below)
+            if constexpr (PK) {            // packed copy: rows of the live lanes only (dead lanes read slot 0: masked below)
                 bool lv;
                 int pp, cn;
                 packed_pos1(G, ti, lane, step, lv, pp, cn);
-                ch = fwd + ((long)tile * G.ptot + G.pref[step]) * (long)NF + pp;
-                rl = cn;
-            }
+                const double2 *ch2 = reinterpret_cast<const double2 *>(fwd + ((long)tile * G.ptot + G.pref[step]) * (long)NF) + pp;
 #pragma unroll
-            for (int e = 0; e < NF; ++e) k.v[e] = ch[(long)e * rl];
+                for (int e = 0; e < NF / 2; ++e) {
+                    const double2 t2 = ch2[(long)e * cn];
+                    k.v[2 * e] = t2.x;
+                    k.v[2 * e + 1] = t2.y;
+                }
+            } else {
+                const double *ch = fwd + (chunk0 + step) * (long)(NF * 64) + lane;
+#pragma unroll
+                for (int e = 0; e < NF; ++e) k.v[e] = ch[(long)e * 64];
+            }
             const long cs = k.ok ? c : park;
 #pragma unroll
             for (int r = 0; r < B; ++r) k.rr[r] = rhs[(long)r * nt + cs];
@@ -1091,12 +1103,28 @@ __global__ __launch_bounds__(64) void k_ilu1_solve(IluGeom G, const double *__re
             }
         };
         load(buf[0], 0);
-        for (int s = 0; s < ns; s += 2) {
-            if (s + 1 < ns) load(buf[1], s + 1);
-            step(buf[0], s);
-            if (s + 1 < ns) {
-                if (s + 2 < ns) load(buf[0], s + 2);
-                step(buf[1], s + 1);
+        if constexpr (PF == 2) {
+            for (int s = 0; s < ns; s += 2) {
+                if (s + 1 < ns) load(buf[1], s + 1);
+                step(buf[0], s);
+                if (s + 1 < ns) {
+                    if (s + 2 < ns) load(buf[0], s + 2);
+                    step(buf[1], s + 1);
+                }
+            }
+        } else {
+            if (1 < ns) load(buf[1], 1);
+            for (int s = 0; s < ns; s += 3) {
+                if (s + 2 < ns) load(buf[2], s + 2);
+                step(buf[0], s);
+                if (s + 1 < ns) {
+                    if (s + 3 < ns) load(buf[0], s + 3);
+                    step(buf[1], s + 1);
+                }
+                if (s + 2 < ns) {
+                    if (s + 4 < ns) load(buf[1], s + 4);
+                    step(buf[2], s + 2);
+                }
             }
         }
     }
@@ -1108,7 +1136,7 @@ __global__ __launch_bounds__(64) void k_ilu1_solve(IluGeom G, const double *__re
 #pragma unroll
             for (int r = 0; r < B; ++r) xh[d][r] = 0.0;
         struct Buf { double v[NB], yy[B], aa[B]; bool ok; long c; };
-        Buf buf[2];
+        Buf buf[3];
         const double *asrc[B];
         double amask[B];
 #pragma unroll
@@ -1120,17 +1148,22 @@ __global__ __launch_bounds__(64) void k_ilu1_solve(IluGeom G, const double *__re
         auto load = [&](Buf &k, int step) {
             k.ok = tile_cell1(G, ti, step, l0, c);
             k.c = k.ok ? c : park;
-            const double *ch = bwd + (chunk0 + step) * (long)(NB * 64) + lane;
-            long rl = 64;
-            if (G.pref) {
+            if constexpr (PK) {
                 bool lv;
                 int pp, cn;
                 packed_pos1(G, ti, lane, step, lv, pp, cn);
-                ch = bwd + ((long)tile * G.ptot + G.pref[step]) * (long)NB + pp;
-                rl = cn;
-            }
+                const double2 *ch2 = reinterpret_cast<const double2 *>(bwd + ((long)tile * G.ptot + G.pref[step]) * (long)NBP) + pp;
 #pragma unroll
-            for (int e = 0; e < NB; ++e) k.v[e] = ch[(long)e * rl];
+                for (int e = 0; e < NBP / 2; ++e) {
+                    const double2 t2 = ch2[(long)e * cn];
+                    k.v[2 * e] = t2.x;
+                    if (2 * e + 1 < NB) k.v[2 * e + 1] = t2.y;
+                }
+            } else {
+                const double *ch = bwd + (chunk0 + step) * (long)(NB * 64) + lane;
+#pragma unroll
+                for (int e = 0; e < NB; ++e) k.v[e] = ch[(long)e * 64];
+            }
             const double *ych = ytmp + (chunk0 + step) * (long)(B * 64) + lane;
 #pragma unroll
             for (int r = 0; r < B; ++r) {
@@ -1171,12 +1204,28 @@ __global__ __launch_bounds__(64) void k_ilu1_solve(IluGeom G, const double *__re
             }
         };
         load(buf[0], ns - 1);
-        for (int s = ns - 1; s >= 0; s -= 2) {
-            if (s - 1 >= 0) load(buf[1], s - 1);
-            step(buf[0], s);
-            if (s - 1 >= 0) {
-                if (s - 2 >= 0) load(buf[0], s - 2);
-                step(buf[1], s - 1);
+        if constexpr (PF == 2) {
+            for (int s = ns - 1; s >= 0; s -= 2) {
+                if (s - 1 >= 0) load(buf[1], s - 1);
+                step(buf[0], s);
+                if (s - 1 >= 0) {
+                    if (s - 2 >= 0) load(buf[0], s - 2);
+                    step(buf[1], s - 1);
+                }
+            }
+        } else {
+            if (ns - 2 >= 0) load(buf[1], ns - 2);
+            for (int s = ns - 1; s >= 0; s -= 3) {
+                if (s - 2 >= 0) load(buf[2], s - 2);
+                step(buf[0], s);
+                if (s - 1 >= 0) {
+                    if (s - 3 >= 0) load(buf[0], s - 3);
+                    step(buf[1], s - 1);
+                }
+                if (s - 2 >= 0) {
+                    if (s - 4 >= 0) load(buf[1], s - 4);
+                    step(buf[2], s - 2);
+                }
             }
         }
     }
@@ -1260,7 +1309,7 @@ void ilu_setup(tp_ctx *c) {
             d.pref.alloc(pf.size());
             copy_sync(c, d.pref.p, pf.data(), sizeof(int) * pf.size(), hipMemcpyHostToDevice);
             d.fwdp.alloc((size_t)d.ntiles * d.ptot * 6 * bb);
-            d.bwdp.alloc((size_t)d.ntiles * d.ptot * 7 * bb);
+            d.bwdp.alloc((size_t)d.ntiles * d.ptot * ((7 * bb + 1) & ~1));      // (rows of entry pairs: k_ilu1_repack)
         } else {
             d.fwdp.free(); d.bwdp.free(); d.pref.free();
         }
@@ -1359,8 +1408,18 @@ void ilu_solve(tp_ctx *c, const double *r, double *x, const double *addto, int n
         const bool pk = c->ilu.ptot > 0;
         if (pk) G1.pref = c->ilu.pref.p;
         const double *ff = pk ? c->ilu.fwdp.p : c->ilu.fwd.p, *bbk = pk ? c->ilu.bwdp.p : c->ilu.bwd.p;
-        if (c->b == 3) hipLaunchKernelGGL((k_ilu1_solve<3>), dim3(c->ilu.ntiles), dim3(64), 0, c->stream, G1, ff, bbk, r, c->ilu.ytmp.p, x, addto, nadd);
-        else           hipLaunchKernelGGL((k_ilu1_solve<2>), dim3(c->ilu.ntiles), dim3(64), 0, c->stream, G1, ff, bbk, r, c->ilu.ytmp.p, x, addto, nadd);
+        static const int pf = getenv("TP_ILU1_PF") ? atoi(getenv("TP_ILU1_PF")) : 3;
+        const dim3 gr(c->ilu.ntiles), bl(64);
+#define TP_ILU1_LAUNCH(BQ, PFQ, PKQ) \
+    hipLaunchKernelGGL((k_ilu1_solve<BQ, PFQ, PKQ>), gr, bl, 0, c->stream, G1, ff, bbk, r, c->ilu.ytmp.p, x, addto, nadd)
+        if (c->b == 3) {
+            if (pk) { if (pf >= 3) TP_ILU1_LAUNCH(3, 3, true); else TP_ILU1_LAUNCH(3, 2, true); }
+            else TP_ILU1_LAUNCH(3, 2, false);
+        } else {
+            if (pk) { if (pf >= 3) TP_ILU1_LAUNCH(2, 3, true); else TP_ILU1_LAUNCH(2, 2, true); }
+            else TP_ILU1_LAUNCH(2, 2, false);
+        }
+#undef TP_ILU1_LAUNCH
         TP_HIP(hipGetLastError());
         return;
     }
