@@ -1,5 +1,5 @@
 """Child process of tests/test_gpu_parity.py::test_env_selected_sweep_kernels: the kernel variants that are selected by
-environment variables read once per process (ILU(0) sweeps: TP_ILU_MW, TP_ILU_BLOCK, TP_ILU_YLDS; ILU(1) sweeps: TP_ILU1_PACK; system AMG: TP_BAMG_*;
+environment variables read once per process (ILU(0) sweeps: TP_ILU_MW, TP_ILU_BLOCK, TP_ILU_YLDS; ILU(1): TP_ILU1_PACK, TP_ILU1_FACTOR_TILE, TP_ILU1_PF; system AMG: TP_BAMG_*;
 LDS-tiled assembly: TP_ASM_LDS) against the oracle."""
 import os
 import sys

@@ -257,9 +257,11 @@ def test_bilu_preset_stage(levels, nphase):
 
 @pytest.mark.parametrize("env", [{"TP_ILU_MW": "0"}, {"TP_ILU_MW": "0", "TP_ILU_YLDS": "0"}, {"TP_ILU_BLOCK": "0"}, {"TP_ILU_BLOCK": "1"},
                                  {"TP_ILU_YLDS": "0"}, {"TP_ILU_YLDS": "0", "TP_ILU_BLOCK": "1"}, {"TP_ASM_LDS": "1"},
-                                 {"TP_ILU1_PACK": "0"}, {"TP_BAMG_TAIL_CELLS": "0", "TP_BAMG_FUSE_BELOW": "0", "TP_BAMG_DENSE_LDS": "0"}],
+                                 {"TP_ILU1_PACK": "0"}, {"TP_ILU1_FACTOR_TILE": "0", "TP_ILU1_PF": "2"},
+                                 {"TP_ILU1_PACK": "0", "TP_ILU1_FACTOR_TILE": "0"},
+                                 {"TP_BAMG_TAIL_CELLS": "0", "TP_BAMG_FUSE_BELOW": "0", "TP_BAMG_DENSE_LDS": "0"}],
                          ids=["one_wave", "one_wave_y_hbm", "mw_per_step", "mw_blocks", "mw_y_hbm", "mw_y_hbm_blocks", "asm_lds_tiled",
-                              "ilu1_padded_stream", "system_amg_per_level_kernels"])
+                              "ilu1_padded_stream", "ilu1_factor_per_step_launches", "ilu1_padded_per_step", "system_amg_per_level_kernels"])
 def test_env_selected_sweep_kernels(env):
     """The ILU(0) sweep kernels that are not the default of a given grid -- the one-wave kernel, the multi-wave kernel with /
     without block transfers and with y through HBM -- are selected by environment variables the library reads once per

@@ -927,13 +927,16 @@ struct Ilu1Upd {           // F[target(IK,IU)] -= L * U_k[IU]
     }
 };
 
-template <int B, int IK>
+// RING: the rows of the last four steps live in an LDS ring [step & 3][entry][64 lanes] (k_ilu1_factor_tile) instead of
+// being read back from the chunk array
+template <int B, int IK, bool RING = false>
 struct Ilu1Elim {          // eliminate the lower entry IK of the row against row k = c + offset(IK)
     static __device__ __forceinline__ void run(double (&F)[13][B * B], const bool (&in)[13], const IluGeom &G,
                                                const double *bwd, long chunk0, int s, int lane) {
         if (in[IK]) {
             constexpr int d0 = ilu1_off(IK, 0), d1 = ilu1_off(IK, 1), d2 = ilu1_off(IK, 2);
-            const double *bk = bwd + (chunk0 + s + d0 + 2 * d1 + 4 * d2) * (long)(7 * B * B * 64) + (lane + d1 + G.t1 * d2);
+            const long row = RING ? (long)((s + d0 + 2 * d1 + 4 * d2) & 3) : chunk0 + s + d0 + 2 * d1 + 4 * d2;
+            const double *bk = bwd + row * (long)(7 * B * B * 64) + (lane + d1 + G.t1 * d2);
             double Dk[B * B], Lck[B * B];
 #pragma unroll
             for (int e = 0; e < B * B; ++e) Dk[e] = bk[(long)(6 * B * B + e) * 64];
@@ -950,7 +953,7 @@ struct Ilu1Elim {          // eliminate the lower entry IK of the row against ro
             for (int e = 0; e < B * B; ++e) F[IK][e] = Lck[e];
             Ilu1Upd<B, IK, 0>::run(F, Lck, bk);
         }
-        if constexpr (IK + 1 < 6) Ilu1Elim<B, IK + 1>::run(F, in, G, bwd, chunk0, s, lane);
+        if constexpr (IK + 1 < 6) Ilu1Elim<B, IK + 1, RING>::run(F, in, G, bwd, chunk0, s, lane);
     }
 };
 
@@ -1006,6 +1009,195 @@ __device__ __forceinline__ void packed_pos1(const IluGeom &G, const TileInfo &t,
     const unsigned long long m = __ballot(live);
     pos = live ? (int)__popcll(m & ((1ull << lane) - 1ull)) : 0;
     cnt = G.pref[s + 1] - G.pref[s];
+}
+
+// The whole factorisation of a tile by ONE workgroup of B wavefronts: steps in order, the rows of the last four steps (upper
+// blocks and D~^-1: what later rows eliminate against) in an LDS ring, the Jacobian read once, the factor written once --
+// straight into the packed rows the sweeps stream (PK) or into padded 64-lane rows.  Wave w owns block-row w of every block of
+// the row being eliminated (L = F D_k^-1 and F -= L U act on block rows independently); only the diagonal block is exchanged
+// (LDS) for its inverse.  k_ilu1_level does the same with one launch per step and reads every row back up to six times
+// (C4: 3.2 ms + 0.5 ms repacking against 1.5 ms here).  What bounds this kernel is neither arithmetic nor latency (a one-wave
+// version, no prefetch, full barriers: the same 1.5 ms; with eliminations AND stores switched off still 1.2 ms): it is the
+// Jacobian read.  The lanes of a step hold cells of 54-64 different grid lines, so each of the 63 plane loads touches one
+// 128-byte line per lane for 8 bytes, and the 16 steps that share a line are ~20 us apart with a working set of 435 KB per
+// tile (13 MB per XCD): the lines are fetched again from the Infinity Cache / HBM every step, a 16x read amplification.  The
+// ILU(0) path avoids it with a chunk-ordered copy of J (k_ilu_gather, one coalesced pass); the same pass here would bring this
+// kernel to roughly 0.4 + 0.4 ms -- 2 % of a Newton step of pc_cprilu1_gmres, not done.
+template <int B, int I>
+struct Ilu1InitRow {       // one block row of the row's entries from a register copy of the cell's seven Jacobian block rows
+    static __device__ __forceinline__ void run(double (&F)[13][B], const bool (&in)[13], const double (&Jc)[7][B]) {
+        constexpr int SL = ilu1_slot(I);
+#pragma unroll
+        for (int q = 0; q < B; ++q) F[I][q] = (SL >= 0 && in[I]) ? Jc[SL < 0 ? 0 : SL][q] : 0.0;
+        if constexpr (I + 1 < 13) Ilu1InitRow<B, I + 1>::run(F, in, Jc);
+    }
+};
+template <int B, int IK, int IU>
+struct Ilu1UpdRow {        // F[target(IK,IU)] -= L * U_k[IU]   (one block row)
+    static __device__ __forceinline__ void run(double (&F)[13][B], const double (&L)[B], const double *bk) {
+        constexpr int TG = ilu1_target(IK, IU);
+        if constexpr (TG >= 0) {
+#pragma unroll
+            for (int q = 0; q < B; ++q) {
+                double v = 0.0;
+#pragma unroll
+                for (int m = 0; m < B; ++m) v += L[m] * bk[(IU * B * B + m * B + q) * 64];
+                F[TG][q] -= v;
+            }
+        }
+        if constexpr (IU + 1 < 6) Ilu1UpdRow<B, IK, IU + 1>::run(F, L, bk);
+    }
+};
+template <int B, int IK>
+struct Ilu1ElimRow {       // eliminate the lower entry IK against row k = c + offset(IK), rows of earlier steps in the LDS ring
+    static __device__ __forceinline__ void run(double (&F)[13][B], const bool (&in)[13], const IluGeom &G, const double *ring,
+                                               int s, int lane) {
+        if (in[IK]) {
+            constexpr int d0 = ilu1_off(IK, 0), d1 = ilu1_off(IK, 1), d2 = ilu1_off(IK, 2);
+            const double *bk = ring + ((s + d0 + 2 * d1 + 4 * d2) & 3) * (7 * B * B * 64) + (lane + d1 + G.t1 * d2);
+            double L[B];
+#pragma unroll
+            for (int q = 0; q < B; ++q) {
+                double v = 0.0;
+#pragma unroll
+                for (int m = 0; m < B; ++m) v += F[IK][m] * bk[(6 * B * B + m * B + q) * 64];
+                L[q] = v;
+            }
+#pragma unroll
+            for (int q = 0; q < B; ++q) F[IK][q] = L[q];
+            Ilu1UpdRow<B, IK, 0>::run(F, L, bk);
+        }
+        if constexpr (IK + 1 < 6) Ilu1ElimRow<B, IK + 1>::run(F, in, G, ring, s, lane);
+    }
+};
+
+// Memory ordering: vmcnt counts loads AND stores and retires in order, so (i) the Jacobian rows of step s+1 are requested BEFORE
+// the factor stores of step s (J, fwd, bwd are deliberately not __restrict__: the compiler then cannot sink the loads below the
+// stores), and (ii) every lane stores on every step (lanes without a packed row into a dump row behind the arrays) and the
+// prefetch is unconditional, so that the wait at the end of a step is a static vmcnt(#stores) instead of vmcnt(0).
+template <int B, bool PK>
+__global__ __launch_bounds__(64 * B) void k_ilu1_factor_tile(IluGeom G, const double *J, double *fwd, double *bwd) {
+    constexpr int BB = B * B, NFE = 6 * BB, NBE = 7 * BB, NBP = (NBE + 1) & ~1;
+    extern __shared__ double ring[];               // [4][NBE][64] rows of the last four steps, then [BB][64] diagonal blocks
+    double *dex = ring + 4 * NBE * 64;
+    // the prefix table of the packed rows, in LDS: read from global memory it is a vector load (the scalar cache is not
+    // coherent with the stores of this kernel) whose vmcnt(0) drains the prefetch in every step
+    int *spref = reinterpret_cast<int *>(dex + BB * 64);
+    if constexpr (PK) {
+        for (int i = threadIdx.x; i <= G.nsteps; i += blockDim.x) spref[i] = G.pref[i];
+        __syncthreads();
+    }
+    const int tile = blockIdx.x, lane = threadIdx.x & 63, w = threadIdx.x >> 6;
+    const TileInfo ti = tile_info(G, tile, lane);
+    const long chunk0 = (long)tile * G.nsteps;
+    // this wave's block row of the cell's seven Jacobian blocks, loaded one step ahead (a lane without a cell reads the
+    // first owned cell and never uses it)
+    double Jn[7][B];
+    int l0n;
+    long cn;
+    bool okn = tile_cell1(G, ti, 0, l0n, cn);
+    {
+        const long cs = okn ? cn : G.g.np;
+#pragma unroll
+        for (int sl = 0; sl < 7; ++sl)
+#pragma unroll
+            for (int q = 0; q < B; ++q) Jn[sl][q] = J[(long)(sl * BB + w * B + q) * G.g.ntot + cs];
+    }
+    for (int s = 0; s < G.nsteps; ++s) {
+        const int l0 = l0n;
+        const bool ok = okn;
+        double Jc[7][B];
+#pragma unroll
+        for (int sl = 0; sl < 7; ++sl)
+#pragma unroll
+            for (int q = 0; q < B; ++q) Jc[sl][q] = Jn[sl][q];
+        {
+            okn = tile_cell1(G, ti, min(s + 1, G.nsteps - 1), l0n, cn);
+            const long cs = okn ? cn : G.g.np;
+#pragma unroll
+            for (int sl = 0; sl < 7; ++sl)
+#pragma unroll
+                for (int q = 0; q < B; ++q) Jn[sl][q] = J[(long)(sl * BB + w * B + q) * G.g.ntot + cs];
+        }
+        bool live = true;
+        int pos = lane, cnt = 64;
+        int prow = 0;
+        if constexpr (PK) {                // (packed_pos1 with the table in LDS)
+            const int lp = s - 2 * ti.j - 4 * ti.k;
+            live = lane < G.nl && lp >= 0 && lp < G.t0;
+            const unsigned long long m = __ballot(live);
+            pos = live ? (int)__popcll(m & ((1ull << lane) - 1ull)) : 0;
+            prow = spref[s];
+            cnt = spref[s + 1] - prow;
+        }
+        double F[13][B];
+        if (ok) {
+            bool in[13];
+#pragma unroll
+            for (int i = 0; i < 13; ++i) {
+                const int a0 = l0 + ilu1_off(i, 0), a1 = ti.j + ilu1_off(i, 1), a2 = ti.k + ilu1_off(i, 2);
+                in[i] = a0 >= 0 && a0 < ti.tt0 && a1 >= 0 && a1 < ti.tj && a2 >= 0 && a2 < ti.tk;
+            }
+            Ilu1InitRow<B, 0>::run(F, in, Jc);
+            Ilu1ElimRow<B, 0>::run(F, in, G, ring, s, lane);
+        } else {
+#pragma unroll
+            for (int i = 0; i < 13; ++i)
+#pragma unroll
+                for (int q = 0; q < B; ++q) F[i][q] = 0.0;
+        }
+#pragma unroll
+        for (int q = 0; q < B; ++q) dex[(w * B + q) * 64 + lane] = F[6][q];
+        TP_LDS_BARRIER();                  // diagonal block complete; every wave is done reading the ring for this step
+        double D[B][B], Di[B][B];
+#pragma unroll
+        for (int r = 0; r < B; ++r)
+#pragma unroll
+            for (int q = 0; q < B; ++q) D[r][q] = ok ? dex[(r * B + q) * 64 + lane] : (r == q ? 1.0 : 0.0);
+        inv_block<B>(D, Di);
+        double *slot = ring + (s & 3) * (NBE * 64) + lane;          // (slot s & 3 held step s - 4)
+#pragma unroll
+        for (int i = 0; i < 6; ++i)
+#pragma unroll
+            for (int q = 0; q < B; ++q) slot[(i * BB + w * B + q) * 64] = F[7 + i][q];
+#pragma unroll
+        for (int q = 0; q < B; ++q) slot[(6 * BB + w * B + q) * 64] = ok ? Di[w][q] : 0.0;
+        {                                  // (padded rows: every lane; lanes without a row store zero blocks)
+            if constexpr (PK) {
+                // lanes without a packed row store into the dump row behind the last tile (64-lane stride)
+                const long row0 = live ? (long)tile * G.ptot + prow : (long)G.ntiles * G.ptot;
+                double *fo = fwd + row0 * (long)NFE + 2 * (live ? pos : lane);
+                double *bo = bwd + row0 * (long)NBP + 2 * (live ? pos : lane);
+                const long ps = live ? 2 * cnt : 128;
+#pragma unroll
+                for (int i = 0; i < 6; ++i)
+#pragma unroll
+                    for (int q = 0; q < B; ++q) {
+                        const int e = i * BB + w * B + q;
+                        fo[(long)(e >> 1) * ps + (e & 1)] = F[i][q];
+                        bo[(long)(e >> 1) * ps + (e & 1)] = F[7 + i][q];
+                    }
+#pragma unroll
+                for (int q = 0; q < B; ++q) {
+                    const int e = 6 * BB + w * B + q;
+                    bo[(long)(e >> 1) * ps + (e & 1)] = ok ? Di[w][q] : 0.0;
+                }
+            } else {
+                double *fch = fwd + (chunk0 + s) * (long)(NFE * 64) + lane;
+                double *bch = bwd + (chunk0 + s) * (long)(NBE * 64) + lane;
+#pragma unroll
+                for (int i = 0; i < 6; ++i)
+#pragma unroll
+                    for (int q = 0; q < B; ++q) {
+                        fch[(long)(i * BB + w * B + q) * 64] = F[i][q];
+                        bch[(long)(i * BB + w * B + q) * 64] = F[7 + i][q];
+                    }
+#pragma unroll
+                for (int q = 0; q < B; ++q) bch[(long)(6 * BB + w * B + q) * 64] = ok ? Di[w][q] : 0.0;
+            }
+        }
+        TP_LDS_BARRIER();                  // the ring slot is complete before the next step reads it
+    }
 }
 
 // padded factor chunks [tile][step][entry][64 lanes] -> packed [tile][step][entry PAIR][live lanes][2] (once per
@@ -1237,6 +1429,12 @@ __global__ __launch_bounds__(64) void k_ilu1_solve(IluGeom G, const double *__re
 // configurations, which are bound by the single wave's instruction issue, lose 15-25 % (C1: 0.24 -> 0.28 ms).
 static bool ilu_compact(const tp_ctx *c) { return c->g.gn2 > 1 && c->ilu.t1 * c->ilu.t2 < 64; }
 
+// ILU(1) factorisation: one wavefront per tile (k_ilu1_factor_tile, default) or one launch per step (k_ilu1_level)
+static bool ilu1_per_tile() {
+    static const bool v = !(getenv("TP_ILU1_FACTOR_TILE") && atoi(getenv("TP_ILU1_FACTOR_TILE")) == 0);
+    return v;
+}
+
 static IluGeom geom_of(const tp_ctx *c) {
     IluGeom G;
     G.g = c->g;
@@ -1290,12 +1488,16 @@ void ilu_setup(tp_ctx *c) {
     c->graph_epoch++;            // new tile layout / factor buffers: captured pc_apply graphs are stale
     if (d.levels) {
         const size_t chunks = (size_t)d.ntiles * d.nsteps, bb = (size_t)c->b * c->b;
-        d.fwd.alloc(chunks * 6 * bb * 64);
-        d.bwd.alloc(chunks * 7 * bb * 64);
+        static const bool pack1 = !(getenv("TP_ILU1_PACK") && atoi(getenv("TP_ILU1_PACK")) == 0);
+        if (pack1 && ilu1_per_tile()) {     // the per-tile factorisation writes the packed rows itself: no padded arrays
+            d.fwd.free(); d.bwd.free();
+        } else {
+            d.fwd.alloc(chunks * 6 * bb * 64);
+            d.bwd.alloc(chunks * 7 * bb * 64);
+        }
         d.ytmp.alloc(chunks * c->b * 64);
         d.jt.free();
         d.whole = false;
-        static const bool pack1 = !(getenv("TP_ILU1_PACK") && atoi(getenv("TP_ILU1_PACK")) == 0);
         d.ptot = 0;
         if (pack1) {
             std::vector<int> pf(d.nsteps + 1, 0);
@@ -1308,8 +1510,9 @@ void ilu_setup(tp_ctx *c) {
             d.ptot = pf[d.nsteps];
             d.pref.alloc(pf.size());
             copy_sync(c, d.pref.p, pf.data(), sizeof(int) * pf.size(), hipMemcpyHostToDevice);
-            d.fwdp.alloc((size_t)d.ntiles * d.ptot * 6 * bb);
-            d.bwdp.alloc((size_t)d.ntiles * d.ptot * ((7 * bb + 1) & ~1));      // (rows of entry pairs: k_ilu1_repack)
+            // (rows of entry pairs: k_ilu1_repack; + one 64-lane dump row for k_ilu1_factor_tile's idle lanes)
+            d.fwdp.alloc(((size_t)d.ntiles * d.ptot + 64) * 6 * bb);
+            d.bwdp.alloc(((size_t)d.ntiles * d.ptot + 64) * ((7 * bb + 1) & ~1));
         } else {
             d.fwdp.free(); d.bwdp.free(); d.pref.free();
         }
@@ -1342,6 +1545,25 @@ void ilu_factor(tp_ctx *c) {
     if (c->ilu.slots == 0) ilu_setup(c);
     const IluGeom G = geom_of(c);
     if (c->ilu.levels) {
+        if (ilu1_per_tile()) {                 // one wavefront per tile, rows of the last four steps in LDS, output in the sweeps' layout
+            const bool pk = c->ilu.ptot > 0;
+            IluGeom Gp = G;
+            if (pk) Gp.pref = c->ilu.pref.p;
+            double *fo = pk ? c->ilu.fwdp.p : c->ilu.fwd.p, *bo = pk ? c->ilu.bwdp.p : c->ilu.bwd.p;
+            const size_t lds = (size_t)(4 * 7 + 1) * c->b * c->b * 64 * sizeof(double) + (size_t)(G.nsteps + 2) * sizeof(int);
+            const dim3 gr(c->ilu.ntiles), bl(64 * c->b);
+#define TP_ILU1_FT(BQ, PKQ)                                                                                               \
+    do {                                                                                                                  \
+        TP_HIP(hipFuncSetAttribute(reinterpret_cast<const void *>(&k_ilu1_factor_tile<BQ, PKQ>),                          \
+                                   hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds));                                \
+        hipLaunchKernelGGL((k_ilu1_factor_tile<BQ, PKQ>), gr, bl, lds, c->stream, Gp, c->J.p, fo, bo);                    \
+    } while (0)
+            if (c->b == 3) { if (pk) TP_ILU1_FT(3, true); else TP_ILU1_FT(3, false); }
+            else           { if (pk) TP_ILU1_FT(2, true); else TP_ILU1_FT(2, false); }
+#undef TP_ILU1_FT
+            TP_HIP(hipGetLastError());
+            return;
+        }
         for (int s = 0; s < G.nsteps; ++s) {
             if (c->b == 3) hipLaunchKernelGGL((k_ilu1_level<3>), dim3(c->ilu.ntiles), dim3(64), 0, c->stream, G, c->J.p, c->ilu.fwd.p, c->ilu.bwd.p, s);
             else           hipLaunchKernelGGL((k_ilu1_level<2>), dim3(c->ilu.ntiles), dim3(64), 0, c->stream, G, c->J.p, c->ilu.fwd.p, c->ilu.bwd.p, s);

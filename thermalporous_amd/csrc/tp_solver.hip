@@ -69,7 +69,7 @@ static void face_strengths(tp_ctx *c, double st[3]) {
 // the captured pc_apply graphs bake in buffer addresses and options: invalidate them when any changes
 static void refresh_pc_signature(tp_ctx *c) {
     const uintptr_t sig[] = {(uintptr_t)c->opA00.base, (uintptr_t)c->opA01.base, (uintptr_t)c->opA10.base,
-                             (uintptr_t)c->Sm.p, (uintptr_t)c->ilu.fwd.p, (uintptr_t)c->amg_p, (uintptr_t)c->amg_T, (uintptr_t)c->bamg,
+                             (uintptr_t)c->Sm.p, (uintptr_t)c->ilu.fwd.p, (uintptr_t)c->ilu.fwdp.p, (uintptr_t)c->amg_p, (uintptr_t)c->amg_T, (uintptr_t)c->bamg,
                              (uintptr_t)c->w1.p, (uintptr_t)c->w3.p, (uintptr_t)c->w4.p, (uintptr_t)c->dcoef.p, (uintptr_t)c->spbuf.p,
                              (uintptr_t)c->opt.amg_nu, (uintptr_t)c->opt.pc_kind, (uintptr_t)c->opt.decoup,
                              (uintptr_t)c->opt.amg_single, (uintptr_t)c->opt.amg_gather_cells, (uintptr_t)c->opt.schur_a11, (uintptr_t)c->opt.fs_additive, (uintptr_t)c->opt.amg_full_levels, (uintptr_t)c->opt.amg_coarse_pre, (uintptr_t)c->opt.amg_coarse_post, (uintptr_t)c->opt.amg_tail_post, (uintptr_t)c->opt.amg_mid_skip,
