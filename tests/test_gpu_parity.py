@@ -56,6 +56,16 @@ CASES = [
     ("c4_2ph_3d_cptr_a11", cases.c4_spe10_3d, dict(Nx=7, Ny=8, Nz=6, nphase=2), dict(pc="cptr", schur_a11=True)),
     ("c4_2ph_3d_cptrQI_a11", cases.c4_spe10_3d, dict(Nx=7, Ny=8, Nz=6, nphase=2), dict(pc="cptr", decoup="QI", schur_a11=True)),
     ("c4_1ph_3d_fs_a11", cases.c4_spe10_3d, dict(Nx=7, Ny=8, Nz=6, nphase=1), dict(pc="fieldsplit_cd", schur_a11=True)),
+    # degenerate boxes: one cell wide in one or two directions, a 2x2x2 cube, a single line, more columns than a wave has lanes
+    ("deg_1x5x7_cptr", cases.c4_spe10_3d, dict(Nx=1, Ny=5, Nz=7, nphase=2), dict(pc="cptr")),
+    ("deg_2x2x2_cptr", cases.c4_spe10_3d, dict(Nx=2, Ny=2, Nz=2, nphase=2), dict(pc="cptr")),
+    ("deg_line_cptr", cases.c4_spe10_3d, dict(Nx=1, Ny=1, Nz=9, nphase=2), dict(pc="cptr")),
+    ("deg_3x4x1_cptr", cases.c4_spe10_3d, dict(Nx=3, Ny=4, Nz=1, nphase=2), dict(pc="cptr")),
+    ("deg_70x3x2_cpr", cases.c4_spe10_3d, dict(Nx=70, Ny=3, Nz=2, nphase=1), dict(pc="cpr")),
+    ("deg_2x2x2_ilu1", cases.c4_spe10_3d, dict(Nx=2, Ny=2, Nz=2, nphase=2), dict(pc="cpr", ilu_levels=1)),
+    ("deg_1x5x7_ilu1", cases.c4_spe10_3d, dict(Nx=1, Ny=5, Nz=7, nphase=2), dict(pc="cpr", ilu_levels=1)),
+    ("deg_1x5x7_whole", cases.c4_spe10_3d, dict(Nx=1, Ny=5, Nz=7, nphase=2), dict(pc="cptr", ilu_whole=True, ilu_tile=(1 << 30, 2, 3))),
+    ("deg_2x3x2_cptramg", cases.c4_spe10_3d, dict(Nx=2, Ny=3, Nz=2, nphase=2), dict(pc="cptramg", decoup="QI")),
     # pc_cptramg[_QI|_TI] (twophase.py:552-566): one system-AMG V-cycle on the 2x2-block (p,T) operator as stage 1
     ("c4_2ph_3d_cptramg", cases.c4_spe10_3d, dict(Nx=7, Ny=13, Nz=9, nphase=2), dict(pc="cptramg")),
     ("c4_2ph_3d_cptramg_QI", cases.c4_spe10_3d, dict(Nx=9, Ny=14, Nz=8, nphase=2), dict(pc="cptramg", decoup="QI")),
