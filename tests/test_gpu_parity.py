@@ -235,6 +235,81 @@ def test_newton_parity(name, builder, kw, opts, dt):
     h.close()
 
 
+def test_ilu_sweeps_random_boxes_and_tiles():
+    """Seeded fuzz of the second stage alone (pc_bilu: pc_apply IS the sweep): random box shapes, tile shapes, fill level,
+    whole-slab coupling and phase count -- partial tiles, tiles wider than the box, one-cell directions -- against the oracle's
+    tiled ILU.  One process, 36 small cases."""
+    rng = np.random.default_rng(20261004)
+    from oracle.engine import OracleEngine
+    from thermalporous_amd.engine import HipEngine
+    for it in range(36):
+        Nx, Ny, Nz = (int(v) for v in rng.integers(1, 13, size=3))
+        if Nx*Ny*Nz < 2:
+            Nz = 3
+        nphase = int(rng.integers(1, 3))
+        levels = int(rng.integers(0, 2))
+        whole = bool(levels == 0 and rng.integers(0, 3) == 0)
+        t1, t2 = int(rng.integers(1, 9)), int(rng.integers(1, 9))
+        t0 = int(rng.choice([1 << 30, 3, 5, 8]))
+        opts = dict(pc="bilu", ilu_levels=levels, ilu_tile=(t0, t1, t2))
+        if whole:
+            opts["ilu_whole"] = True
+        tag = (it, Nx, Ny, Nz, nphase, opts)
+        spec, u0, *_ = cases.c4_spe10_3d(Nx=Nx, Ny=Ny, Nz=Nz, nphase=nphase)
+        o, h = OracleEngine(spec, opts), HipEngine(spec, opts)
+        u = cases.perturbed_state(spec, seed=5 + it, amp=0.3)
+        for e in (o, h):
+            e.set_old(u0)
+            e.set_dt(8640.0)
+            e.set_state(u)
+        J = o.jacobian()
+        h.jacobian()
+        o.pc.setup(J)
+        h.pc_setup()
+        x = rng.standard_normal(u.shape)
+        h.vec_set("x", x)
+        h.pc_apply("x", "y")
+        assert rel2(h.vec_get("y"), o.pc.ilu.solve(x)) < 1e-10, tag
+        h.close()
+
+
+def test_pc_apply_random_boxes_and_cycle_shapes():
+    """Seeded fuzz of the whole preconditioner: random box shapes (up to ~8000 cells: several AMG levels, tail, pairs of
+    transfer levels), presets, decouplings and cycle-shape options against the oracle."""
+    rng = np.random.default_rng(4102026)
+    from oracle.engine import OracleEngine
+    from thermalporous_amd.engine import HipEngine
+    kinds = [dict(pc="cptr"), dict(pc="cptr", decoup="QI"), dict(pc="cpr", decoup="QI"), dict(pc="cpr"), dict(pc="cptramg", decoup="QI"),
+             dict(pc="cptr", schur_a11=True), dict(pc="cpr", ilu_levels=1)]
+    for it in range(20):
+        Nx, Ny, Nz = int(rng.integers(2, 17)), int(rng.integers(2, 25)), int(rng.integers(1, 21))
+        opts = dict(kinds[int(rng.integers(0, len(kinds)))])
+        nphase = 2 if opts["pc"] in ("cptramg",) or rng.integers(0, 3) else 1
+        if nphase == 1 and opts["pc"] == "cptr":
+            opts = dict(pc="cpr", decoup="TI")
+        opts.update(amg_full_levels=int(rng.integers(0, 4)), amg_coarse_pre=int(rng.integers(0, 2)), amg_coarse_post=int(rng.integers(1, 3)),
+                    amg_mid_skip=bool(rng.integers(0, 2)), amg_tail_post=int(rng.integers(1, 3)), amg_nu=int(rng.integers(1, 3)))
+        tag = (it, Nx, Ny, Nz, nphase, opts)
+        spec, u0, *_ = cases.c4_spe10_3d(Nx=Nx, Ny=Ny, Nz=Nz, nphase=nphase)
+        o, h = OracleEngine(spec, opts), HipEngine(spec, opts)
+        u = cases.perturbed_state(spec, seed=50 + it, amp=0.3)
+        for e in (o, h):
+            e.set_old(u0)
+            e.set_dt(8640.0)
+            e.set_state(u)
+        schur = opts["pc"] == "cptr"
+        out = o.jacobian(want_schur=schur)
+        J, Sm = out if schur else (out, None)
+        h.jacobian()
+        o.pc.setup(J, Sm)
+        h.pc_setup()
+        x = rng.standard_normal(u.shape)
+        h.vec_set("x", x)
+        h.pc_apply("x", "y")
+        assert rel2(h.vec_get("y"), o.pc.apply(x)) < 1e-8, tag
+        h.close()
+
+
 @pytest.mark.parametrize("levels,nphase", [(0, 2), (1, 2), (1, 1)])
 def test_bilu_preset_stage(levels, nphase):
     """pc_bilu (twophase.py:758-762, singlephase.py:402-406): bjacobi + block-ILU(levels) alone -- pc_apply IS the sweep,
