@@ -55,7 +55,7 @@ def run_slabs(spec, opts, u0, dts, nranks):
     return infos, state
 
 
-def run_linear_stage(spec, opts, u0, u, dt, xs, nranks):
+def run_linear_stage(spec, opts, u0, u, dt, xs, nranks, vcycles=True):
     """pc_setup on every slab, then the pressure V-cycle, (S~ V-cycle,) stage 1 and the whole pc_apply of the
     global vector xs; returns the assembled global results and the AMG layout of rank 0."""
     from thermalporous_amd import engine as E
@@ -76,9 +76,11 @@ def run_linear_stage(spec, opts, u0, u, dt, xs, nranks):
             h.pc_setup()
             h.vec_set("x", xs)
             res = {}
-            h.amg_vcycle(0, "x", 0, "v0", 0)
-            res["v0"] = h.vec_get("v0")[0]
-            if opts["pc"] == "cptr":
+            # (the system-AMG presets have no scalar pressure hierarchy; tp_amg_vcycle is not exported for replicated hierarchies)
+            if vcycles and opts["pc"] != "cptramg":
+                h.amg_vcycle(0, "x", 0, "v0", 0)
+                res["v0"] = h.vec_get("v0")[0]
+            if vcycles and opts["pc"] == "cptr":
                 h.amg_vcycle(1, "x", 1, "v1", 1)
                 res["v1"] = h.vec_get("v1")[1]
             h.vec_set("x", xs)
@@ -87,7 +89,7 @@ def run_linear_stage(spec, opts, u0, u, dt, xs, nranks):
             h.vec_set("x", xs)
             h.pc_apply("x", "pc")
             res["pc"] = h.vec_get("pc")
-            out[rank] = (res, h.amg_layout(0), h.amg_trunc(1)[0] if opts["pc"] == "cptr" else None)
+            out[rank] = (res, h.amg_layout(2 if opts["pc"] == "cptramg" else 0), h.amg_trunc(1)[0] if opts["pc"] == "cptr" else None)
             h.close()
         except Exception as e:      # noqa: BLE001
             err.append((rank, repr(e)))
@@ -151,6 +153,41 @@ def test_distributed_amg_levels_equal_the_single_slab_hierarchy(name, kw, opts, 
     J, Sm = jo if schur else (jo, None)
     o.pc.setup(J, Sm)
     assert rel2(many["pc"], o.pc.apply(xs)) < (2e-6 if opts.get("amg_single") else 1e-9)
+
+
+def test_random_boxes_on_random_slab_counts():
+    """Seeded fuzz of the N-slab linear stage: random boxes, 2-5 slabs (ragged slab heights), random gather thresholds (replicated,
+    partly and fully distributed hierarchies), presets and cycle shapes.  Stage 1 equals the single slab's to round-off, the whole
+    pc_apply equals the N-slab oracle's."""
+    from oracle.engine import OracleEngine
+    rng = np.random.default_rng(510)
+    kinds = [dict(pc="cptr"), dict(pc="cptr", decoup="QI"), dict(pc="cpr", decoup="QI"), dict(pc="cptramg", decoup="QI"),
+             dict(pc="cptr", ilu_whole=True, ilu_tile=(4, 3, 3))]
+    for it in range(10):
+        nranks = int(rng.integers(2, 6))
+        Nx, Nz = int(rng.integers(2, 9)), int(rng.integers(2, 8))
+        Ny = int(rng.integers(max(2*nranks, 9), 34))                # the longest direction carries the slabs
+        opts = dict(kinds[int(rng.integers(0, len(kinds)))])
+        nphase = 2 if opts["pc"] != "cpr" or rng.integers(0, 2) else 1
+        opts.update(amg_gather_cells=int(rng.choice([0, 100, 400, 2000000])), amg_full_levels=int(rng.integers(0, 4)),
+                    amg_mid_skip=bool(rng.integers(0, 2)), amg_nu=int(rng.integers(1, 3)))
+        tag = (it, nranks, Nx, Ny, Nz, nphase, opts)
+        spec, u0, *_ = cases.c4_spe10_3d(Nx=Nx, Ny=Ny, Nz=Nz, nphase=nphase)
+        u = cases.perturbed_state(spec, seed=70 + it, amp=0.2)
+        xs = rng.standard_normal(u.shape)
+        dt = 3000.0
+        one, _, _ = run_linear_stage(spec, opts, u0, u, dt, xs, 1, vcycles=False)
+        many, _, _ = run_linear_stage(spec, opts, u0, u, dt, xs, nranks, vcycles=False)
+        assert rel2(many["s1"], one["s1"]) < 1e-10, tag
+        o = OracleEngine(spec, dict(opts, nslabs=nranks))
+        o.set_old(u0)
+        o.set_dt(dt)
+        o.set_state(u)
+        schur = opts["pc"] == "cptr"
+        jo = o.jacobian(want_schur=schur)
+        J, Sm = jo if schur else (jo, None)
+        o.pc.setup(J, Sm)
+        assert rel2(many["pc"], o.pc.apply(xs)) < 1e-9, tag
 
 
 SLAB_CASES = [
