@@ -171,42 +171,46 @@ __global__ void k_amg_dense_inverse(GridDev g, StencilT<R> A, int n, double *M, 
     }
 }
 
-// same, with the augmented matrix [M | I] held in LDS (n <= 64: 64 KiB) -- ~10x fewer global round trips
+// same, with the augmented matrix [M | I] held in LDS (n <= 64: 64 KiB, rows padded to 64 columns so that an element index
+// splits into (row, column) by shift and mask) -- no global round trips, 1024 threads, three barriers per pivot: the pivot
+// column is copied aside first, so the rank-1 update of a pivot is ONE phase for both halves.  Same operations in the same
+// order as the global-memory kernel (bit-identical inverse); C4: 136 -> ~30 us per hierarchy and set-up.
 template <class R>
-__global__ __launch_bounds__(256) void k_amg_dense_inverse_lds(GridDev g, StencilT<R> A, int n, double *Minv_out) {
+__global__ __launch_bounds__(1024) void k_amg_dense_inverse_lds(GridDev g, StencilT<R> A, int n, double *Minv_out) {
     __shared__ double M[64 * 64];
     __shared__ double I[64 * 64];
+    __shared__ double col[64];
+    const int t = threadIdx.x, T = blockDim.x;
     const long off[7] = {0, -1, 1, -(long)g.n0, (long)g.n0, -g.np, g.np};
-    for (int e = threadIdx.x; e < n * n; e += blockDim.x) { M[e] = 0.0; I[e] = (e / n == e % n) ? 1.0 : 0.0; }
+    for (int e = t; e < 64 * 64; e += T) { M[e] = 0.0; I[e] = ((e >> 6) == (e & 63)) ? 1.0 : 0.0; }
     __syncthreads();
-    for (int r = threadIdx.x; r < n; r += blockDim.x) {
+    for (int r = t; r < n; r += T) {
         const long c = g.np + r;
         int i0, i1, i2;
         cell_ijk(g, r, i0, i1, i2);
         const bool has[7] = {true, i0 > 0, i0 < g.n0 - 1, i1 > 0, i1 < g.n1 - 1, i2 > 0, i2 < g.n2 - 1};
         for (int s = 0; s < 7; ++s)
-            if (has[s]) M[r * n + (int)(r + off[s])] += (double)A.slot(s)[c];
+            if (has[s]) M[r * 64 + (int)(r + off[s])] += (double)A.slot(s)[c];
     }
     __syncthreads();
     for (int p = 0; p < n; ++p) {
-        const double piv = M[p * n + p];
+        if (t < n) col[t] = M[t * 64 + p];
         __syncthreads();
-        for (int e = threadIdx.x; e < n; e += blockDim.x) { M[p * n + e] /= piv; I[p * n + e] /= piv; }
+        const double piv = col[p];
+        if (t < n) M[p * 64 + t] /= piv;
+        else if (t >= 64 && t < 64 + n) I[p * 64 + (t - 64)] /= piv;
         __syncthreads();
-        // eliminate column p from every other row: thread (r, q) updates both halves
-        for (int e = threadIdx.x; e < n * n; e += blockDim.x) {
-            const int r = e / n, q = e % n;
-            if (r == p) continue;
-            const double fct = M[r * n + p];
-            I[r * n + q] -= fct * I[p * n + q];
-            if (q != p) M[r * n + q] -= fct * M[p * n + q];
+        // eliminate column p from every other row: thread (r, q) updates both halves (M[r][p] becomes fct - fct * 1 = 0)
+        for (int e = t; e < n * 64; e += T) {
+            const int r = e >> 6, q = e & 63;
+            if (r == p || q >= n) continue;
+            const double fct = col[r];
+            I[e] -= fct * I[p * 64 + q];
+            M[e] = (q == p) ? 0.0 : M[e] - fct * M[p * 64 + q];
         }
         __syncthreads();
-        for (int r = threadIdx.x; r < n; r += blockDim.x)
-            if (r != p) M[r * n + p] = 0.0;
-        __syncthreads();
     }
-    for (int e = threadIdx.x; e < n * n; e += blockDim.x) Minv_out[e] = I[e];
+    for (int e = t; e < n * n; e += T) Minv_out[e] = I[(e / n) * 64 + e % n];
 }
 
 // ---- per-cell building blocks of the cycle (shared by the per-level kernels and the tail kernel) ------
@@ -870,7 +874,7 @@ static void setup_impl(tp_ctx *c, Amg *amg, const Stencil &A0) {
     static const bool skip_dense = getenv("TP_EXP_SKIP_DENSE") && atoi(getenv("TP_EXP_SKIP_DENSE")) == 1;
     if (skip_dense && amg->dense_done) {
     } else if (n <= 64)
-        hipLaunchKernelGGL(k_amg_dense_inverse_lds<R>, dim3(1), dim3(256), 0, c->stream, Lc->g, opc, n,
+        hipLaunchKernelGGL(k_amg_dense_inverse_lds<R>, dim3(1), dim3(1024), 0, c->stream, Lc->g, opc, n,
                            amg->coarse_inv.p + (size_t)n * n);
     else
         hipLaunchKernelGGL(k_amg_dense_inverse<R>, dim3(1), dim3(256), 0, c->stream, Lc->g, opc, n, amg->coarse_inv.p,
