@@ -257,6 +257,7 @@ tp_ctx::~tp_ctx() {
     }
     if (ev_fork) (void)hipEventDestroy(ev_fork);
     if (stream) (void)hipStreamDestroy(stream);
+    if (h_pin) (void)hipHostFree(h_pin);
 }
 
 using namespace tp;
@@ -322,6 +323,7 @@ int tp_create(const tp_grid *grid, const tp_params *prm, const tp_options *opt, 
     c->vol = grid->h[0] * grid->h[1] * grid->h[2];
     derive_params(c);
     TP_HIP(hipStreamCreateWithFlags(&c->stream, hipStreamNonBlocking));      // (never tied to the legacy stream: tp_common.hpp)
+    TP_HIP(hipHostMalloc((void **)&c->h_pin, sizeof(double) * tp_ctx::H_PIN, hipHostMallocMapped));
     for (int i = 0; i < 2; ++i) {
         TP_HIP(hipStreamCreateWithFlags(&c->aux[i], hipStreamNonBlocking));
         TP_HIP(hipEventCreateWithFlags(&c->ev_join[i], hipEventDisableTiming));

@@ -265,6 +265,8 @@ struct tp_ctx {
     tp::GridDev gfull;
     tp::DBuf<double> gA00, gA01, gA10, gSm, gvec;   // operators: 7 planes each; gvec: work vectors
     long vcycles = 0;
+    static constexpr int H_PIN = 1024;   // doubles of pinned, device-mapped host memory the reductions write their results to
+    double *h_pin = nullptr;
     long gather_override = -2;     // != -2: replaces tp_options.amg_gather_cells in amg_build (selfp on several GPUs: 0)
     tp_ksp_monitor_fn monitor = nullptr;      // per-field true-residual monitor (ksp_monitor_residuals)
     void *monitor_user = nullptr;

@@ -124,8 +124,10 @@ __global__ __launch_bounds__(256) void k_multi_dot(GridDev g, int nf, const doub
 
 // second stage of the deterministic two-stage sums: one workgroup per output.  Latency bound (a few thousand
 // partials): 1024 threads with 4 independent loads in flight each, fixed summation order.
+// out2 (optional): a second destination -- the pinned, device-mapped host buffer tp_ctx::h_pin, so that the host can read
+// the sums after the stream synchronisation without a device-to-host copy in between (a blit kernel of ~4.5 us)
 __global__ __launch_bounds__(1024) void k_reduce_partials(const double *__restrict__ partial, long nwaves,
-                                                          double *__restrict__ out) {
+                                                          double *__restrict__ out, double *__restrict__ out2 = nullptr) {
     __shared__ double sh[16];
     const double *p = partial + (long)blockIdx.x * nwaves;
     double s0 = 0.0, s1 = 0.0, s2 = 0.0, s3 = 0.0;
@@ -142,6 +144,7 @@ __global__ __launch_bounds__(1024) void k_reduce_partials(const double *__restri
 #pragma unroll
         for (int w = 0; w < 16; ++w) t += sh[w];
         out[blockIdx.x] = t;
+        if (out2) out2[blockIdx.x] = t;
     }
 }
 
@@ -159,6 +162,24 @@ static long md_nwaves(const tp_ctx *c, int nf) {
     const long nall = c->g.nown * nf;
     return (nall + 64L * md_chunk() - 1) / (64L * md_chunk());
 }
+// second stage of a reduction + hand-over to the host: n sums of nw partials -> red_out (device) and host_out.  One GPU: the
+// kernel also writes to the pinned buffer and the host copies from there after the synchronisation; several GPUs: all-reduce,
+// then a device-to-host copy.
+static void reduce_to_host(tp_ctx *c, long nw, int n, double *host_out) {
+    static const bool use_pin = !(getenv("TP_PIN") && atoi(getenv("TP_PIN")) == 0);
+    double *pin = (use_pin && !c->dist && n <= tp_ctx::H_PIN) ? c->h_pin : nullptr;
+    hipLaunchKernelGGL(k_reduce_partials, dim3(n), dim3(1024), 0, c->stream, c->gs_partial.p, nw, c->red_out.p, pin);
+    TP_HIP(hipGetLastError());
+    allreduce_sum(c, c->red_out.p, n);
+    if (pin) {
+        TP_HIP(hipStreamSynchronize(c->stream));
+        memcpy(host_out, pin, sizeof(double) * n);
+        return;
+    }
+    TP_HIP(hipMemcpyAsync(host_out, c->red_out.p, sizeof(double) * n, hipMemcpyDeviceToHost, c->stream));
+    TP_HIP(hipStreamSynchronize(c->stream));
+}
+
 #define TP_MD_LAUNCH(KERNEL, ...)                                                                              \
     do {                                                                                                       \
         if (md_chunk() == 4) hipLaunchKernelGGL(KERNEL<4>, __VA_ARGS__);                                       \
@@ -173,11 +194,7 @@ void multi_dot(tp_ctx *c, int nf, const double *V, long vstride, int k, const do
     if ((long)c->red_out.n < nout) c->red_out.alloc(nout + 64);
     TP_MD_LAUNCH(k_multi_dot, md_grid(nw), dim3(256), 0, c->stream, c->g, nf, V, vstride, k, w, w2,
                  c->gs_partial.p, nw);
-    hipLaunchKernelGGL(k_reduce_partials, dim3(nout), dim3(1024), 0, c->stream, c->gs_partial.p, nw, c->red_out.p);
-    TP_HIP(hipGetLastError());
-    allreduce_sum(c, c->red_out.p, nout);
-    TP_HIP(hipMemcpyAsync(host_out, c->red_out.p, sizeof(double) * nout, hipMemcpyDeviceToHost, c->stream));
-    TP_HIP(hipStreamSynchronize(c->stream));
+    reduce_to_host(c, nw, nout, host_out);
 }
 
 // ||x_i||^2 of several vectors with ONE reduction launch, ONE all-reduce and ONE host sync (the three norms of SNES's
@@ -189,11 +206,7 @@ void multi_norm2sq(tp_ctx *c, int nf, int nvec, const double *const *x, double *
     for (int i = 0; i < nvec; ++i)
         TP_MD_LAUNCH(k_multi_dot, md_grid(nw), dim3(256), 0, c->stream, c->g, nf, x[i], 0L, 0, x[i], x[i],
                      c->gs_partial.p + (long)i * nw, nw);
-    hipLaunchKernelGGL(k_reduce_partials, dim3(nvec), dim3(1024), 0, c->stream, c->gs_partial.p, nw, c->red_out.p);
-    TP_HIP(hipGetLastError());
-    allreduce_sum(c, c->red_out.p, nvec);
-    TP_HIP(hipMemcpyAsync(host_out, c->red_out.p, sizeof(double) * nvec, hipMemcpyDeviceToHost, c->stream));
-    TP_HIP(hipStreamSynchronize(c->stream));
+    reduce_to_host(c, nw, nvec, host_out);
 }
 
 double norm2(tp_ctx *c, int nf, const double *x) {
@@ -310,14 +323,23 @@ void orthogonalize(tp_ctx *c, int nf, const double *V, long vstride, int k, doub
     // a lagged normalisation (two more vector passes and one wasted iteration per solve) for ~10 us of ~700: not adopted.
     TP_MD_LAUNCH(k_multi_dot, md_grid(nw), dim3(256), 0, c->stream, c->g, nf, V, vstride, k, w,
                  (const double *)nullptr, c->gs_partial.p, nw);
-    hipLaunchKernelGGL(k_reduce_partials, dim3(k), dim3(1024), 0, c->stream, c->gs_partial.p, nw, c->red_out.p);
+    // one GPU: the sums also go straight to pinned host memory (no copy between the last kernel and the host's wake-up)
+    static const bool use_pin = !(getenv("TP_PIN") && atoi(getenv("TP_PIN")) == 0);
+    double *pin = (use_pin && !c->dist && k + 1 <= tp_ctx::H_PIN) ? c->h_pin : nullptr;
+    hipLaunchKernelGGL(k_reduce_partials, dim3(k), dim3(1024), 0, c->stream, c->gs_partial.p, nw, c->red_out.p, pin);
     allreduce_sum(c, c->red_out.p, k);
     static const int gs_rev = !(getenv("TP_GS_REVERSE") && atoi(getenv("TP_GS_REVERSE")) == 0);
     TP_MD_LAUNCH(k_multi_axpy_norm, md_grid(nw), dim3(256), 0, c->stream, c->g, nf, V, vstride, k,
                  c->red_out.p, w, c->gs_partial.p, nw, gs_rev);
-    hipLaunchKernelGGL(k_reduce_partials, dim3(1), dim3(1024), 0, c->stream, c->gs_partial.p, nw, c->red_out.p + k);
+    hipLaunchKernelGGL(k_reduce_partials, dim3(1), dim3(1024), 0, c->stream, c->gs_partial.p, nw, c->red_out.p + k,
+                       pin ? pin + k : (double *)nullptr);
     TP_HIP(hipGetLastError());
     allreduce_sum(c, c->red_out.p + k, 1);
+    if (pin) {
+        TP_HIP(hipStreamSynchronize(c->stream));
+        memcpy(host_out, pin, sizeof(double) * (k + 1));
+        return;
+    }
     TP_HIP(hipMemcpyAsync(host_out, c->red_out.p, sizeof(double) * (k + 1), hipMemcpyDeviceToHost, c->stream));
     TP_HIP(hipStreamSynchronize(c->stream));
 }
