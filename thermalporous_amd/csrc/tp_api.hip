@@ -258,6 +258,7 @@ tp_ctx::~tp_ctx() {
     if (ev_fork) (void)hipEventDestroy(ev_fork);
     if (stream) (void)hipStreamDestroy(stream);
     if (h_pin) (void)hipHostFree(h_pin);
+    if (ev_h) (void)hipEventDestroy(ev_h);
 }
 
 using namespace tp;
@@ -324,6 +325,7 @@ int tp_create(const tp_grid *grid, const tp_params *prm, const tp_options *opt, 
     derive_params(c);
     TP_HIP(hipStreamCreateWithFlags(&c->stream, hipStreamNonBlocking));      // (never tied to the legacy stream: tp_common.hpp)
     TP_HIP(hipHostMalloc((void **)&c->h_pin, sizeof(double) * tp_ctx::H_PIN, hipHostMallocMapped));
+    TP_HIP(hipEventCreateWithFlags(&c->ev_h, hipEventDisableTiming));
     for (int i = 0; i < 2; ++i) {
         TP_HIP(hipStreamCreateWithFlags(&c->aux[i], hipStreamNonBlocking));
         TP_HIP(hipEventCreateWithFlags(&c->ev_join[i], hipEventDisableTiming));

@@ -267,6 +267,7 @@ struct tp_ctx {
     long vcycles = 0;
     static constexpr int H_PIN = 1024;   // doubles of pinned, device-mapped host memory the reductions write their results to
     double *h_pin = nullptr;
+    hipEvent_t ev_h = nullptr;           // recorded behind the reductions of an orthogonalisation (pipelined FGMRES loop)
     long gather_override = -2;     // != -2: replaces tp_options.amg_gather_cells in amg_build (selfp on several GPUs: 0)
     tp_ksp_monitor_fn monitor = nullptr;      // per-field true-residual monitor (ksp_monitor_residuals)
     void *monitor_user = nullptr;
@@ -299,6 +300,11 @@ double norm2(tp_ctx *c, int nf, const double *x);
 void multi_norm2sq(tp_ctx *c, int nf, int nvec, const double *const *x, double *host_out);   // host_out[i] = <x_i, x_i>
 // h = V^T w ; w -= V h ; host_out[0..k-1] = h, host_out[k] = ||w||^2  (one host sync)
 void orthogonalize(tp_ctx *c, int nf, const double *V, long vstride, int k, double *w, double *host_out);
+bool orthogonalize_can_split(const tp_ctx *c, int k);
+void orthogonalize_enqueue(tp_ctx *c, int nf, const double *V, long vstride, int k, double *w);
+const double *orthogonalize_norm_dev(const tp_ctx *c, int k);
+void orthogonalize_wait(tp_ctx *c, int k, double *host_out);
+void vec_scale_dev_norm(tp_ctx *c, int nf, const double *n2_dev, double *x);   // x *= 1/sqrt(*n2_dev) (owned)
 void field_minmax(tp_ctx *c, const double *x, double *lo, double *hi);
 void field_clamp01(tp_ctx *c, double *x);
 // stencil operators

@@ -37,6 +37,20 @@ void vec_copy(tp_ctx *c, const double *x, double *y, long n) {
 void vec_axpy_owned(tp_ctx *c, int nf, double a, const double *x, double *y) {
     hipLaunchKernelGGL(k_axpy_owned<true>, grid_for(c->g.nown * nf), dim3(256), 0, c->stream, c->g, nf, a, x, y);
 }
+// x[f][c] *= 1 / sqrt(*n2) over owned cells: v_{j+1} = w / ||w|| with the norm still on the device (the same IEEE operations
+// as the host's 1.0 / sqrt(n2) followed by vec_scale_to: bit-identical)
+__global__ void k_scale_dev_norm(GridDev g, int nf, const double *__restrict__ n2, double *x) {
+    const long t = (long)blockIdx.x * blockDim.x + threadIdx.x;
+    if (t >= g.nown * nf) return;
+    const double a = 1.0 / sqrt(*n2);
+    const long f = t / g.nown, i = t - f * g.nown;
+    const long c = f * g.ntot + g.np + i;
+    x[c] = a * x[c];
+}
+void vec_scale_dev_norm(tp_ctx *c, int nf, const double *n2_dev, double *x) {
+    hipLaunchKernelGGL(k_scale_dev_norm, grid_for(c->g.nown * nf), dim3(256), 0, c->stream, c->g, nf, n2_dev, x);
+}
+
 void vec_scale_to(tp_ctx *c, int nf, double a, const double *x, double *y) {
     hipLaunchKernelGGL(k_axpy_owned<false>, grid_for(c->g.nown * nf), dim3(256), 0, c->stream, c->g, nf, a, x, y);
 }
@@ -336,12 +350,33 @@ void orthogonalize(tp_ctx *c, int nf, const double *V, long vstride, int k, doub
     TP_HIP(hipGetLastError());
     allreduce_sum(c, c->red_out.p + k, 1);
     if (pin) {
+        if (!host_out) {                   // split form (orthogonalize_enqueue / orthogonalize_wait): the caller goes on enqueueing
+            TP_HIP(hipEventRecord(c->ev_h, c->stream));
+            return;
+        }
         TP_HIP(hipStreamSynchronize(c->stream));
         memcpy(host_out, pin, sizeof(double) * (k + 1));
         return;
     }
+    TP_REQUIRE(host_out, "split orthogonalisation needs the pinned result buffer");
     TP_HIP(hipMemcpyAsync(host_out, c->red_out.p, sizeof(double) * (k + 1), hipMemcpyDeviceToHost, c->stream));
     TP_HIP(hipStreamSynchronize(c->stream));
+}
+
+// The same in two halves for the pipelined FGMRES loop (one GPU): enqueue the kernels and record an event; later wait for that
+// event only -- whatever was enqueued behind it (the next iteration's preconditioner application) keeps running -- and read the
+// k dots and ||w||^2 from the pinned buffer.  ||w||^2 also stays on the device at orthogonalize_norm_dev(c, k).
+bool orthogonalize_can_split(const tp_ctx *c, int k) {
+    static const bool use_pin = !(getenv("TP_PIN") && atoi(getenv("TP_PIN")) == 0);
+    return use_pin && !c->dist && k + 1 <= tp_ctx::H_PIN;
+}
+void orthogonalize_enqueue(tp_ctx *c, int nf, const double *V, long vstride, int k, double *w) {
+    orthogonalize(c, nf, V, vstride, k, w, nullptr);
+}
+const double *orthogonalize_norm_dev(const tp_ctx *c, int k) { return c->red_out.p + k; }
+void orthogonalize_wait(tp_ctx *c, int k, double *host_out) {
+    TP_HIP(hipEventSynchronize(c->ev_h));
+    memcpy(host_out, c->h_pin, sizeof(double) * (k + 1));
 }
 
 // ---- saturation guard (thermalmodel.py:193-229): min/max and clamp of one field over owned cells -----

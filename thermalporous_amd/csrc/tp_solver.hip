@@ -493,12 +493,38 @@ int fgmres(tp_ctx *c, const double *bvec, double *x, int *its_out, double *rnorm
         vec_scale_to(c, B, 1.0 / beta, rsrc, c->V.p);                      // v0 = r/beta
         int k = 0, reason = 0;
         double res = beta;
+        // One GPU: the loop is PIPELINED.  The host needs h (Givens rotations, convergence test) once per iteration; waiting for
+        // it with the stream empty leaves the GPU idle for a host wake-up plus a launch latency (~40 us of a 1.1 ms iteration).
+        // Instead v_{j+1} = w / ||w|| is formed from the norm on the device and z_{j+1} = M^-1 v_{j+1}, J z_{j+1} are enqueued
+        // BEFORE the host waits -- on an event behind the reductions, not on the stream.  Speculative: if iteration j turns out
+        // to be the last, that work is discarded (~0.9 ms), so it is only issued while the residual, extrapolated with the last
+        // reduction factor, stays 4x above the tolerance.  Same arithmetic either way (bit-identical iterates).
+        static const bool pipe_on = !(getenv("TP_FGMRES_PIPE") && atoi(getenv("TP_FGMRES_PIPE")) == 0);
+        bool have_w = false;               // z_j, w = J z_j already enqueued by the previous iteration
+        double res_prev = beta, rate = 1.0;
         for (int j = 0; j < m; ++j) {
-            ensure_basis(j + 2);
+            const bool pipe = pipe_on && !c->monitor && orthogonalize_can_split(c, j + 2);
+            ensure_basis(j + (pipe ? 3 : 2));
             double *vj = c->V.p + (long)j * nv, *zj = c->Z.p + (long)j * nv, *w = c->V.p + (long)(j + 1) * nv;
-            pc_apply(c, vj, zj);                                            // z_j = M^-1 v_j
-            spmv_block_halo(c, c->J.p, zj, w);                              // w = J z_j (multi-GPU: exchange of z_j's halos overlapped)
-            orthogonalize(c, B, c->V.p, nv, j + 1, w, hcol.data());         // h = V^T w ; w -= V h ; ||w||^2
+            if (!have_w) {
+                pc_apply(c, vj, zj);                                        // z_j = M^-1 v_j
+                spmv_block_halo(c, c->J.p, zj, w);                          // w = J z_j (multi-GPU: exchange of z_j's halos overlapped)
+            }
+            have_w = false;
+            bool spec = false;
+            if (pipe) {
+                orthogonalize_enqueue(c, B, c->V.p, nv, j + 1, w);          // h = V^T w ; w -= V h ; ||w||^2 (no host wait yet)
+                spec = j + 1 < m && its + 1 < maxit && res_prev * std::min(rate, 1.0) > 4.0 * tol;      // (predicted res_j)
+                if (spec) {
+                    vec_scale_dev_norm(c, B, orthogonalize_norm_dev(c, j + 1), w);          // v_{j+1} = w/||w||
+                    pc_apply(c, w, c->Z.p + (long)(j + 1) * nv);
+                    spmv_block_halo(c, c->J.p, c->Z.p + (long)(j + 1) * nv, c->V.p + (long)(j + 2) * nv);
+                    have_w = true;
+                }
+                orthogonalize_wait(c, j + 1, hcol.data());
+            } else {
+                orthogonalize(c, B, c->V.p, nv, j + 1, w, hcol.data());     // h = V^T w ; w -= V h ; ||w||^2
+            }
             const double hn = std::sqrt(hcol[j + 1]);
             for (int i = 0; i <= j; ++i) H[(size_t)i * m + j] = hcol[i];
             H[(size_t)(j + 1) * m + j] = hn;
@@ -537,10 +563,14 @@ int fgmres(tp_ctx *c, const double *bvec, double *x, int *its_out, double *rnorm
                 for (int f = 0; f < B; ++f) { const double *one[1] = {fp[f]}; multi_norm2sq(c, 1, 1, one, &fn[f]); fn[f] = std::sqrt(fn[f]); }
                 c->monitor(its, res, fn.data(), B, c->monitor_user);
             }
-            if (!std::isfinite(res)) { reason = -9; break; }               // KSP_DIVERGED_NANORINF
-            if (res <= tol) { reason = 2; break; }
-            if (hn == 0.0) { reason = 2; break; }
-            vec_scale_to(c, B, 1.0 / hn, w, w);                             // v_{j+1} = w/||w||
+            rate = res_prev > 0.0 ? res / res_prev : 1.0;
+            res_prev = res;
+            if (!std::isfinite(res) || res <= tol || hn == 0.0) {
+                if (have_w) c->vcycles -= c->opt.pc_kind == 4 ? 0 : c->opt.fs_additive ? 2 : schur_of(c->opt) ? 3 : 1;   // (discarded application)
+                reason = !std::isfinite(res) ? -9 : 2;                     // KSP_DIVERGED_NANORINF | converged (or happy breakdown)
+                break;
+            }
+            if (!spec) vec_scale_to(c, B, 1.0 / hn, w, w);                  // v_{j+1} = w/||w||
         }
         // y = H^-1 g ; x += Z y
         yk.assign(k, 0.0);
