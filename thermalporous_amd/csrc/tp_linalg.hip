@@ -358,17 +358,24 @@ void orthogonalize(tp_ctx *c, int nf, const double *V, long vstride, int k, doub
         memcpy(host_out, pin, sizeof(double) * (k + 1));
         return;
     }
-    TP_REQUIRE(host_out, "split orthogonalisation needs the pinned result buffer");
+    if (!host_out) {                       // split form on several GPUs: the all-reduced sums -> pinned buffer (asynchronous), event
+        TP_REQUIRE(k + 1 <= tp_ctx::H_PIN, "split orthogonalisation needs the pinned result buffer");
+        TP_HIP(hipMemcpyAsync(c->h_pin, c->red_out.p, sizeof(double) * (k + 1), hipMemcpyDeviceToHost, c->stream));
+        TP_HIP(hipEventRecord(c->ev_h, c->stream));
+        return;
+    }
     TP_HIP(hipMemcpyAsync(host_out, c->red_out.p, sizeof(double) * (k + 1), hipMemcpyDeviceToHost, c->stream));
     TP_HIP(hipStreamSynchronize(c->stream));
 }
 
-// The same in two halves for the pipelined FGMRES loop (one GPU): enqueue the kernels and record an event; later wait for that
-// event only -- whatever was enqueued behind it (the next iteration's preconditioner application) keeps running -- and read the
-// k dots and ||w||^2 from the pinned buffer.  ||w||^2 also stays on the device at orthogonalize_norm_dev(c, k).
+// The same in two halves for the pipelined FGMRES loop: enqueue the kernels (and all-reduces) and record an event; later wait
+// for that event only -- whatever was enqueued behind it (the next iteration's preconditioner application) keeps running -- and
+// read the k dots and ||w||^2 from the pinned buffer.  ||w||^2 also stays on the device at orthogonalize_norm_dev(c, k).
+// Several GPUs: every rank holds the same all-reduced sums, takes the same speculation decision and therefore issues the same
+// sequence of collectives.
 bool orthogonalize_can_split(const tp_ctx *c, int k) {
     static const bool use_pin = !(getenv("TP_PIN") && atoi(getenv("TP_PIN")) == 0);
-    return use_pin && !c->dist && k + 1 <= tp_ctx::H_PIN;
+    return use_pin && k + 1 <= tp_ctx::H_PIN;
 }
 void orthogonalize_enqueue(tp_ctx *c, int nf, const double *V, long vstride, int k, double *w) {
     orthogonalize(c, nf, V, vstride, k, w, nullptr);

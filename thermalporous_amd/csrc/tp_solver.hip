@@ -493,7 +493,7 @@ int fgmres(tp_ctx *c, const double *bvec, double *x, int *its_out, double *rnorm
         vec_scale_to(c, B, 1.0 / beta, rsrc, c->V.p);                      // v0 = r/beta
         int k = 0, reason = 0;
         double res = beta;
-        // One GPU: the loop is PIPELINED.  The host needs h (Givens rotations, convergence test) once per iteration; waiting for
+        // The loop is PIPELINED.  The host needs h (Givens rotations, convergence test) once per iteration; waiting for
         // it with the stream empty leaves the GPU idle for a host wake-up plus a launch latency (~40 us of a 1.1 ms iteration).
         // Instead v_{j+1} = w / ||w|| is formed from the norm on the device and z_{j+1} = M^-1 v_{j+1}, J z_{j+1} are enqueued
         // BEFORE the host waits -- on an event behind the reductions, not on the stream.  Speculative: if iteration j turns out
