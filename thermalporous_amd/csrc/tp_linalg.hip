@@ -190,6 +190,12 @@ static void reduce_to_host(tp_ctx *c, long nw, int n, double *host_out) {
         memcpy(host_out, pin, sizeof(double) * n);
         return;
     }
+    if (use_pin && n <= tp_ctx::H_PIN) {   // several GPUs: the all-reduced sums through the pinned buffer (a truly asynchronous copy)
+        TP_HIP(hipMemcpyAsync(c->h_pin, c->red_out.p, sizeof(double) * n, hipMemcpyDeviceToHost, c->stream));
+        TP_HIP(hipStreamSynchronize(c->stream));
+        memcpy(host_out, c->h_pin, sizeof(double) * n);
+        return;
+    }
     TP_HIP(hipMemcpyAsync(host_out, c->red_out.p, sizeof(double) * n, hipMemcpyDeviceToHost, c->stream));
     TP_HIP(hipStreamSynchronize(c->stream));
 }
