@@ -235,6 +235,42 @@ def test_newton_parity(name, builder, kw, opts, dt):
     h.close()
 
 
+def test_newton_random_boxes_and_presets():
+    """Seeded fuzz of whole Newton solves (two time steps each): random boxes, presets and time steps; the same convergence
+    reason and Newton count, Krylov counts within 10 %, states to 1e-8 -- through the pipelined FGMRES loop, the speculative
+    preconditioner applications included."""
+    rng = np.random.default_rng(77)
+    from oracle.engine import OracleEngine
+    from thermalporous_amd.engine import HipEngine
+    kinds = [dict(pc="cptr"), dict(pc="cpr"), dict(pc="cpr", decoup="QI"), dict(pc="cptr", decoup="QI"), dict(pc="cpr", ilu_levels=1),
+             dict(pc="cptramg", decoup="QI"), dict(pc="bilu", ilu_levels=1), dict(pc="cptr", ilu_whole=True, ilu_tile=(4, 3, 3))]
+    for it in range(10):
+        Nx, Ny, Nz = int(rng.integers(2, 9)), int(rng.integers(3, 15)), int(rng.integers(1, 10))
+        opts = dict(kinds[int(rng.integers(0, len(kinds)))], ksp_rtol=1e-8, snes_max_it=25)
+        nphase = 2 if opts["pc"] in ("cptr", "cptramg") or rng.integers(0, 2) else 1
+        dt = float(rng.choice([43.2, 86.4, 432.0]))
+        tag = (it, Nx, Ny, Nz, nphase, opts, dt)
+        spec, u0, *_ = cases.c4_spe10_3d(Nx=Nx, Ny=Ny, Nz=Nz, nphase=nphase)
+        o, h = OracleEngine(spec, opts), HipEngine(spec, opts)
+        for e in (o, h):
+            e.set_state(u0)
+        for step in range(2):
+            for e in (o, h):
+                e.set_old(e.get_state() if e is o else None)
+                e.set_dt(dt)
+            ro, rh = o.newton_solve(), h.newton_solve()
+            assert rh["reason"] == ro["reason"], (tag, ro, rh)
+            if ro["reason"] <= 0:
+                break
+            assert rh["nits"] == ro["nits"], (tag, ro, rh)
+            assert abs(rh["lits"] - ro["lits"]) <= max(2, 0.1*ro["lits"]), (tag, ro, rh)
+            uo, uh = o.get_state(), h.get_state()
+            assert rel2(uh[0], uo[0]) < 1e-8 and rel2(uh[1], uo[1]) < 1e-8, tag
+            if o.b == 3:
+                assert np.abs(uh[2] - uo[2]).max() < 1e-8, tag
+        h.close()
+
+
 def test_ilu_sweeps_random_boxes_and_tiles():
     """Seeded fuzz of the second stage alone (pc_bilu: pc_apply IS the sweep): random box shapes, tile shapes, fill level,
     whole-slab coupling and phase count -- partial tiles, tiles wider than the box, one-cell directions -- against the oracle's
