@@ -235,6 +235,42 @@ def test_newton_parity(name, builder, kw, opts, dt):
     h.close()
 
 
+@pytest.mark.parametrize("mfma", ["1", "0"], ids=["matrix_cores", "scalar"])
+def test_coarse_inverse_kernels(mfma):
+    """TP_AMG_DENSE_MFMA (read at every set-up): the coarsest-grid inverse by a blocked Gauss-Jordan whose trailing update runs on
+    v_mfma_f64_16x16x4_f64 (default) or by the scalar LDS kernel -- the V-cycle and the whole preconditioner against the oracle,
+    full (64-cell) and padded coarsest grids."""
+    import os
+    from oracle.engine import OracleEngine
+    from thermalporous_amd.engine import HipEngine
+    os.environ["TP_AMG_DENSE_MFMA"] = mfma
+    try:
+        for kw in (dict(Nx=16, Ny=18, Nz=16, nphase=2), dict(Nx=9, Ny=14, Nz=8, nphase=2), dict(Nx=7, Ny=5, Nz=3, nphase=1)):
+            opts = dict(pc="cptr" if kw["nphase"] == 2 else "cpr")
+            spec, u0, *_ = cases.c4_spe10_3d(**kw)
+            o, h = OracleEngine(spec, opts), HipEngine(spec, opts)
+            u = cases.perturbed_state(spec, seed=5, amp=0.3)
+            for e in (o, h):
+                e.set_old(u0)
+                e.set_dt(8640.0)
+                e.set_state(u)
+            schur = opts["pc"] == "cptr"
+            out = o.jacobian(want_schur=schur)
+            J, Sm = out if schur else (out, None)
+            h.jacobian()
+            o.pc.setup(J, Sm)
+            h.pc_setup()
+            x = np.random.default_rng(11).standard_normal(u.shape)
+            h.vec_set("x", x)
+            h.amg_vcycle(0, "x", 0, "y", 0)
+            assert rel2(h.vec_get("y")[0], o.pc.amg_p.vcycle(x[0])) < 1e-10, kw
+            h.pc_apply("x", "y")
+            assert rel2(h.vec_get("y"), o.pc.apply(x)) < 1e-10, kw
+            h.close()
+    finally:
+        del os.environ["TP_AMG_DENSE_MFMA"]
+
+
 def test_newton_random_boxes_and_presets():
     """Seeded fuzz of whole Newton solves (two time steps each): random boxes, presets and time steps; the same convergence
     reason and Newton count, Krylov counts within 10 %, states to 1e-8 -- through the pipelined FGMRES loop, the speculative

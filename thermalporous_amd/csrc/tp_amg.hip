@@ -221,6 +221,99 @@ __global__ __launch_bounds__(1024) void k_amg_dense_inverse_lds(GridDev g, Stenc
     for (int e = t; e < n * n; e += T) Minv_out[e] = I[(e / n) * 64 + e % n];
 }
 
+// The MFMA experiment of north_star ("MFMA only in the batched small dense block factor/solve"): the same inverse as a BLOCKED
+// Gauss-Jordan, four pivots at a time, whose trailing update [M | I] -= C R (C: the 64 x 4 multipliers, R: the 4 x 128 scaled
+// pivot rows) is a rank-4 GEMM on v_mfma_f64_16x16x4_f64 -- 4 x 8 output tiles of 16 x 16, two per wave of a 1024-thread
+// workgroup.  Operand maps (cdna_hip_programming.md): A[row = lane & 15][k = lane >> 4], B[k = lane >> 4][col = lane & 15],
+// C/D[row = (lane >> 4) + 4 reg][col = lane & 15].  16 block steps of three barriers instead of 64 pivots of three; not
+// bit-identical with the scalar kernel (different association), same inverse to round-off.  The default since it won (31 against 58 us on C4);
+// TP_AMG_DENSE_MFMA=0 selects the scalar kernel; the measured comparison is in DESIGN.md 4.5.
+typedef double mfma_d4 __attribute__((ext_vector_type(4)));
+template <class R>
+__global__ __launch_bounds__(1024) void k_amg_dense_inverse_mfma(GridDev g, StencilT<R> A, int n, double *Minv_out) {
+    extern __shared__ double lds[];
+    double *X = lds;                       // [64][128]: [M | I], row stride 128
+    double *Rb = X + 64 * 128;             // [4][128] scaled pivot rows
+    double *Cb = Rb + 4 * 128;             // [64][4] multipliers (pivot rows: 0)
+    double *Pi = Cb + 64 * 4;              // [4][4] inverse of the pivot block
+    const int t = threadIdx.x, T = blockDim.x, lane = t & 63, wave = t >> 6;
+    const long off[7] = {0, -1, 1, -(long)g.n0, (long)g.n0, -g.np, g.np};
+    for (int e = t; e < 64 * 128; e += T) {
+        const int r = e >> 7, q = e & 127;
+        X[e] = (q == r + 64 || (q == r && r >= n)) ? 1.0 : 0.0;          // identity half; unit diagonal in the padding rows
+    }
+    __syncthreads();
+    for (int r = t; r < n; r += T) {
+        const long c = g.np + r;
+        int i0, i1, i2;
+        cell_ijk(g, r, i0, i1, i2);
+        const bool has[7] = {true, i0 > 0, i0 < g.n0 - 1, i1 > 0, i1 < g.n1 - 1, i2 > 0, i2 < g.n2 - 1};
+        for (int s = 0; s < 7; ++s)
+            if (has[s]) X[r * 128 + (int)(r + off[s])] += (double)A.slot(s)[c];
+    }
+    __syncthreads();
+    for (int p0 = 0; p0 < 64; p0 += 4) {
+        // (1) inverse of the 4 x 4 pivot block: Gauss-Jordan in the registers of one thread
+        if (t == 0) {
+            double P[4][4], Q[4][4];
+#pragma unroll
+            for (int i = 0; i < 4; ++i)
+#pragma unroll
+                for (int j = 0; j < 4; ++j) { P[i][j] = X[(p0 + i) * 128 + p0 + j]; Q[i][j] = i == j ? 1.0 : 0.0; }
+#pragma unroll
+            for (int p = 0; p < 4; ++p) {
+                const double ip = 1.0 / P[p][p];
+#pragma unroll
+                for (int j = 0; j < 4; ++j) { P[p][j] *= ip; Q[p][j] *= ip; }
+#pragma unroll
+                for (int i = 0; i < 4; ++i) {
+                    if (i == p) continue;
+                    const double f = P[i][p];
+#pragma unroll
+                    for (int j = 0; j < 4; ++j) { P[i][j] -= f * P[p][j]; Q[i][j] -= f * Q[p][j]; }
+                }
+            }
+#pragma unroll
+            for (int i = 0; i < 4; ++i)
+#pragma unroll
+                for (int j = 0; j < 4; ++j) Pi[i * 4 + j] = Q[i][j];
+        }
+        __syncthreads();
+        // (2) R = P^-1 [M | I](pivot rows, :) and the multipliers C = M(:, pivot columns), zero in the pivot rows
+        if (t < 512) {
+            const int i = t >> 7, q = t & 127;
+            double v = 0.0;
+#pragma unroll
+            for (int m = 0; m < 4; ++m) v += Pi[i * 4 + m] * X[(p0 + m) * 128 + q];
+            Rb[i * 128 + q] = v;
+        } else if (t < 768) {
+            const int r = (t - 512) >> 2, j = t & 3;
+            Cb[r * 4 + j] = (r >= p0 && r < p0 + 4) ? 0.0 : X[r * 128 + p0 + j];
+        }
+        __syncthreads();
+        // (3) [M | I] -= C R on the matrix cores: wave w owns the tiles (row tile w >> 2, column tiles 2 (w & 3), + 1);
+        //     the pivot rows (C = 0 there) take R itself
+#pragma unroll
+        for (int h = 0; h < 2; ++h) {
+            const int rt = wave >> 2, ct = 2 * (wave & 3) + h;
+            const double a = -Cb[(rt * 16 + (lane & 15)) * 4 + (lane >> 4)];
+            const double b = Rb[(lane >> 4) * 128 + ct * 16 + (lane & 15)];
+            mfma_d4 acc;
+            double *xp = X + (rt * 16 + (lane >> 4)) * 128 + ct * 16 + (lane & 15);
+#pragma unroll
+            for (int q = 0; q < 4; ++q) acc[q] = xp[q * 4 * 128];
+            acc = __builtin_amdgcn_mfma_f64_16x16x4f64(a, b, acc, 0, 0, 0);
+#pragma unroll
+            for (int q = 0; q < 4; ++q) {
+                const int row = rt * 16 + (lane >> 4) + 4 * q;
+                xp[q * 4 * 128] = (row >= p0 && row < p0 + 4) ? Rb[(row - p0) * 128 + ct * 16 + (lane & 15)] : acc[q];
+            }
+        }
+        __syncthreads();
+    }
+    for (int e = t; e < n * n; e += T) Minv_out[e] = X[(e / n) * 128 + 64 + e % n];
+}
+
 // ---- per-cell building blocks of the cycle (shared by the per-level kernels and the tail kernel) ------
 template <class R>
 struct LevelDevT {
@@ -882,9 +975,19 @@ static void setup_impl(tp_ctx *c, Amg *amg, const Stencil &A0) {
     // inverse, e.g. a blocked Gauss-Jordan on v_mfma_f64_16x16x4, could gain on pc_setup: DESIGN.md 4.5)
     static const bool skip_dense = getenv("TP_EXP_SKIP_DENSE") && atoi(getenv("TP_EXP_SKIP_DENSE")) == 1;
     if (skip_dense && amg->dense_done) {
-    } else if (n <= 64)
-        hipLaunchKernelGGL(k_amg_dense_inverse_lds<R>, dim3(1), dim3(1024), 0, c->stream, Lc->g, opc, n,
-                           amg->coarse_inv.p + (size_t)n * n);
+    } else if (n <= 64) {
+        const bool mfma = !(getenv("TP_AMG_DENSE_MFMA") && atoi(getenv("TP_AMG_DENSE_MFMA")) == 0);  // (read per set-up: A/B in one process)
+        if (mfma) {
+            const int bytes = (64 * 128 + 4 * 128 + 64 * 4 + 16) * (int)sizeof(double);
+            TP_HIP(hipFuncSetAttribute(reinterpret_cast<const void *>(&k_amg_dense_inverse_mfma<R>),
+                                       hipFuncAttributeMaxDynamicSharedMemorySize, bytes));
+            hipLaunchKernelGGL(k_amg_dense_inverse_mfma<R>, dim3(1), dim3(1024), bytes, c->stream, Lc->g, opc, n,
+                               amg->coarse_inv.p + (size_t)n * n);
+        } else {
+            hipLaunchKernelGGL(k_amg_dense_inverse_lds<R>, dim3(1), dim3(1024), 0, c->stream, Lc->g, opc, n,
+                               amg->coarse_inv.p + (size_t)n * n);
+        }
+    }
     else
         hipLaunchKernelGGL(k_amg_dense_inverse<R>, dim3(1), dim3(256), 0, c->stream, Lc->g, opc, n, amg->coarse_inv.p,
                            amg->coarse_inv.p + (size_t)n * n);
