@@ -240,6 +240,9 @@ void allreduce_max(tp_ctx *c, double *dev, int n) {
 }  // namespace tp
 
 tp_ctx::~tp_ctx() {
+    if (getenv("TP_DEBUG") && spec_issued + spec_skipped > 0)
+        fprintf(stderr, "[tp] pipelined FGMRES: %ld speculative applications issued, %ld discarded, %ld iterations without one\n",
+                spec_issued, spec_wasted, spec_skipped);
     for (auto *v : vecs) delete v;
     delete amg_p;
     delete amg_T;

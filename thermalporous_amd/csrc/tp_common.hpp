@@ -265,6 +265,7 @@ struct tp_ctx {
     tp::GridDev gfull;
     tp::DBuf<double> gA00, gA01, gA10, gSm, gvec;   // operators: 7 planes each; gvec: work vectors
     long vcycles = 0;
+    long spec_issued = 0, spec_wasted = 0, spec_skipped = 0;   // pipelined FGMRES loop: speculative applications issued / discarded / iterations run without one (TP_DEBUG)
     static constexpr int H_PIN = 1024;   // doubles of pinned, device-mapped host memory the reductions write their results to
     double *h_pin = nullptr;
     hipEvent_t ev_h = nullptr;           // recorded behind the reductions of an orthogonalisation (pipelined FGMRES loop)

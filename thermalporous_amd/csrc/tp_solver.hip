@@ -500,6 +500,7 @@ int fgmres(tp_ctx *c, const double *bvec, double *x, int *its_out, double *rnorm
         // to be the last, that work is discarded (~0.9 ms), so it is only issued while the residual, extrapolated with the last
         // reduction factor, stays 4x above the tolerance.  Same arithmetic either way (bit-identical iterates).
         static const bool pipe_on = !(getenv("TP_FGMRES_PIPE") && atoi(getenv("TP_FGMRES_PIPE")) == 0);
+        static const double spec_margin = getenv("TP_SPEC_MARGIN") ? atof(getenv("TP_SPEC_MARGIN")) : 4.0;
         bool have_w = false;               // z_j, w = J z_j already enqueued by the previous iteration
         double res_prev = beta, rate = 1.0;
         for (int j = 0; j < m; ++j) {
@@ -514,7 +515,8 @@ int fgmres(tp_ctx *c, const double *bvec, double *x, int *its_out, double *rnorm
             bool spec = false;
             if (pipe) {
                 orthogonalize_enqueue(c, B, c->V.p, nv, j + 1, w);          // h = V^T w ; w -= V h ; ||w||^2 (no host wait yet)
-                spec = j + 1 < m && its + 1 < maxit && res_prev * std::min(rate, 1.0) > 4.0 * tol;      // (predicted res_j)
+                spec = j + 1 < m && its + 1 < maxit && res_prev * std::min(rate, 1.0) > spec_margin * tol;      // (predicted res_j)
+                if (spec) ++c->spec_issued; else ++c->spec_skipped;
                 if (spec) {
                     vec_scale_dev_norm(c, B, orthogonalize_norm_dev(c, j + 1), w);          // v_{j+1} = w/||w||
                     pc_apply(c, w, c->Z.p + (long)(j + 1) * nv);
@@ -566,6 +568,7 @@ int fgmres(tp_ctx *c, const double *bvec, double *x, int *its_out, double *rnorm
             rate = res_prev > 0.0 ? res / res_prev : 1.0;
             res_prev = res;
             if (!std::isfinite(res) || res <= tol || hn == 0.0) {
+                if (have_w) ++c->spec_wasted;
                 if (have_w) c->vcycles -= c->opt.pc_kind == 4 ? 0 : c->opt.fs_additive ? 2 : schur_of(c->opt) ? 3 : 1;   // (discarded application)
                 reason = !std::isfinite(res) ? -9 : 2;                     // KSP_DIVERGED_NANORINF | converged (or happy breakdown)
                 break;
