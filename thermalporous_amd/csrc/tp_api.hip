@@ -327,8 +327,10 @@ int tp_create(const tp_grid *grid, const tp_params *prm, const tp_options *opt, 
     c->vol = grid->h[0] * grid->h[1] * grid->h[2];
     derive_params(c);
     TP_HIP(hipStreamCreateWithFlags(&c->stream, hipStreamNonBlocking));      // (never tied to the legacy stream: tp_common.hpp)
-    TP_HIP(hipHostMalloc((void **)&c->h_pin, sizeof(double) * tp_ctx::H_PIN, hipHostMallocMapped));
-    TP_HIP(hipEventCreateWithFlags(&c->ev_h, hipEventDisableTiming));
+    // coherent (fine-grained) host memory and a system-scope release at the event: the host reads what the reduction kernel
+    // wrote after waiting for ev_h only, not for the stream
+    TP_HIP(hipHostMalloc((void **)&c->h_pin, sizeof(double) * tp_ctx::H_PIN, hipHostMallocMapped | hipHostMallocCoherent));
+    TP_HIP(hipEventCreateWithFlags(&c->ev_h, hipEventDisableTiming | hipEventReleaseToSystem));
     for (int i = 0; i < 2; ++i) {
         TP_HIP(hipStreamCreateWithFlags(&c->aux[i], hipStreamNonBlocking));
         TP_HIP(hipEventCreateWithFlags(&c->ev_join[i], hipEventDisableTiming));
