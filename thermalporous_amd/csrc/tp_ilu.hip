@@ -1228,6 +1228,22 @@ __global__ __launch_bounds__(64) void k_ilu1_solve(IluGeom G, const double *__re
                                                    const double *addto, int nadd) {
     constexpr int BB = B * B, NF = 6 * BB, NB = 7 * BB, NBP = (NB + 1) & ~1;
     static_assert(NF % 2 == 0, "forward rows are loaded in pairs");
+    // the prefix table of the packed rows in LDS: read from global memory it is a VECTOR load (this kernel stores, so the
+    // scalar cache may not be used) whose result is needed at once for the chunk address -- and vmcnt retires in order, so
+    // that wait drained every prefetched chunk at every step
+    extern __shared__ int spref[];
+    if constexpr (PK) {
+        for (int i = threadIdx.x; i <= G.nsteps; i += 64) spref[i] = G.pref[i];
+        __syncthreads();
+    }
+    auto ppos = [&](const TileInfo &t, int ln, int st, int &pp, int &row0, int &cn) __attribute__((always_inline)) {
+        const int lq = st - 2 * t.j - 4 * t.k;
+        const bool lv = ln < G.nl && lq >= 0 && lq < G.t0;
+        const unsigned long long m = __ballot(lv);
+        pp = lv ? (int)__popcll(m & ((1ull << ln) - 1ull)) : 0;
+        row0 = spref[st];
+        cn = spref[st + 1] - row0;
+    };
     const int tile = blockIdx.x, lane = threadIdx.x;
     const long nt = G.g.ntot;
     const TileInfo ti = tile_info(G, tile, lane);
@@ -1249,10 +1265,9 @@ __global__ __launch_bounds__(64) void k_ilu1_solve(IluGeom G, const double *__re
         auto load = [&](Buf &k, int step) {
             k.ok = tile_cell1(G, ti, step, l0, c);
             if constexpr (PK) {            // packed copy: rows of the live lanes only (dead lanes read slot 0: masked below)
-                bool lv;
-                int pp, cn;
-                packed_pos1(G, ti, lane, step, lv, pp, cn);
-                const double2 *ch2 = reinterpret_cast<const double2 *>(fwd + ((long)tile * G.ptot + G.pref[step]) * (long)NF) + pp;
+                int pp, r0, cn;
+                ppos(ti, lane, step, pp, r0, cn);
+                const double2 *ch2 = reinterpret_cast<const double2 *>(fwd + ((long)tile * G.ptot + r0) * (long)NF) + pp;
 #pragma unroll
                 for (int e = 0; e < NF / 2; ++e) {
                     const double2 t2 = ch2[(long)e * cn];
@@ -1305,18 +1320,21 @@ __global__ __launch_bounds__(64) void k_ilu1_solve(IluGeom G, const double *__re
                 }
             }
         } else {
-            if (1 < ns) load(buf[1], 1);
-            for (int s = 0; s < ns; s += 3) {
-                if (s + 2 < ns) load(buf[2], s + 2);
+            // three whole steps per trip and no condition inside: every load is issued (step index clamped: the last trips
+            // re-read the last chunk), so the waits are static vmcnt(N) that leave the two younger chunks in flight
+            load(buf[1], min(1, ns - 1));
+            int s = 0;
+            for (; s + 3 <= ns; s += 3) {
+                load(buf[2], min(s + 2, ns - 1));
                 step(buf[0], s);
-                if (s + 1 < ns) {
-                    if (s + 3 < ns) load(buf[0], s + 3);
-                    step(buf[1], s + 1);
-                }
-                if (s + 2 < ns) {
-                    if (s + 4 < ns) load(buf[1], s + 4);
-                    step(buf[2], s + 2);
-                }
+                load(buf[0], min(s + 3, ns - 1));
+                step(buf[1], s + 1);
+                load(buf[1], min(s + 4, ns - 1));
+                step(buf[2], s + 2);
+            }
+            if (s < ns) {
+                step(buf[0], s);
+                if (s + 1 < ns) step(buf[1], s + 1);
             }
         }
     }
@@ -1341,10 +1359,9 @@ __global__ __launch_bounds__(64) void k_ilu1_solve(IluGeom G, const double *__re
             k.ok = tile_cell1(G, ti, step, l0, c);
             k.c = k.ok ? c : park;
             if constexpr (PK) {
-                bool lv;
-                int pp, cn;
-                packed_pos1(G, ti, lane, step, lv, pp, cn);
-                const double2 *ch2 = reinterpret_cast<const double2 *>(bwd + ((long)tile * G.ptot + G.pref[step]) * (long)NBP) + pp;
+                int pp, r0, cn;
+                ppos(ti, lane, step, pp, r0, cn);
+                const double2 *ch2 = reinterpret_cast<const double2 *>(bwd + ((long)tile * G.ptot + r0) * (long)NBP) + pp;
 #pragma unroll
                 for (int e = 0; e < NBP / 2; ++e) {
                     const double2 t2 = ch2[(long)e * cn];
@@ -1406,18 +1423,19 @@ __global__ __launch_bounds__(64) void k_ilu1_solve(IluGeom G, const double *__re
                 }
             }
         } else {
-            if (ns - 2 >= 0) load(buf[1], ns - 2);
-            for (int s = ns - 1; s >= 0; s -= 3) {
-                if (s - 2 >= 0) load(buf[2], s - 2);
+            load(buf[1], max(ns - 2, 0));
+            int s = ns - 1;
+            for (; s - 2 >= 0; s -= 3) {
+                load(buf[2], max(s - 2, 0));
                 step(buf[0], s);
-                if (s - 1 >= 0) {
-                    if (s - 3 >= 0) load(buf[0], s - 3);
-                    step(buf[1], s - 1);
-                }
-                if (s - 2 >= 0) {
-                    if (s - 4 >= 0) load(buf[1], s - 4);
-                    step(buf[2], s - 2);
-                }
+                load(buf[0], max(s - 3, 0));
+                step(buf[1], s - 1);
+                load(buf[1], max(s - 4, 0));
+                step(buf[2], s - 2);
+            }
+            if (s >= 0) {
+                step(buf[0], s);
+                if (s - 1 >= 0) step(buf[1], s - 1);
             }
         }
     }
@@ -1633,7 +1651,7 @@ void ilu_solve(tp_ctx *c, const double *r, double *x, const double *addto, int n
         static const int pf = getenv("TP_ILU1_PF") ? atoi(getenv("TP_ILU1_PF")) : 3;
         const dim3 gr(c->ilu.ntiles), bl(64);
 #define TP_ILU1_LAUNCH(BQ, PFQ, PKQ) \
-    hipLaunchKernelGGL((k_ilu1_solve<BQ, PFQ, PKQ>), gr, bl, 0, c->stream, G1, ff, bbk, r, c->ilu.ytmp.p, x, addto, nadd)
+    hipLaunchKernelGGL((k_ilu1_solve<BQ, PFQ, PKQ>), gr, bl, (size_t)(G.nsteps + 2) * sizeof(int), c->stream, G1, ff, bbk, r, c->ilu.ytmp.p, x, addto, nadd)
         if (c->b == 3) {
             if (pk) { if (pf >= 3) TP_ILU1_LAUNCH(3, 3, true); else TP_ILU1_LAUNCH(3, 2, true); }
             else TP_ILU1_LAUNCH(3, 2, false);
