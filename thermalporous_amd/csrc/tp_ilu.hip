@@ -169,7 +169,11 @@ __global__ __launch_bounds__(64 * ILU_SEG) void k_ilu_gather(IluGeom G, const do
 
 // MW: the factor is written in the layout of the multi-wave sweep (k_ilu_solve_mw): one run of doubles per block ROW,
 // [tile][step][row r][entry (a, q)][lane] -- forward 3B entries per row (B_a[r][q]), backward 4B (C_a[r][q], then D~^-1[r][q])
-template <int B, bool CP, bool MW>
+// (vmcnt counts loads and stores and retires in order: every condition around a load or a store -- a run-time `if (live)`, the
+// whole-slab branch, `if (s + 1 < ns) load` -- makes the compiler wait with vmcnt(0) at the next use and drains the prefetched
+// chunk.  Hence: WS is a template parameter, lanes without a column store into a dump chunk behind the arrays, and the loop body
+// is two unconditional steps with clamped prefetch indices.)
+template <int B, bool CP, bool MW, bool WS = false>
 __global__ __launch_bounds__(64) void k_ilu_factor(IluGeom G, const double *__restrict__ Jt, double *fwd,
                                                    double *bwd, const int *__restrict__ tiles) {
     using L = IluLayout<B>;
@@ -249,7 +253,7 @@ __global__ __launch_bounds__(64) void k_ilu_factor(IluGeom G, const double *__re
             }
         double D[B][B], Di[B][B];
         constexpr int PFR = (3 * B + 1) / 2, PBR = (4 * B + 1) / 2;       // (IluMwLayout)
-        if (MW && G.ws) {
+        if constexpr (MW && WS) {
             // whole-slab ILU(0): a lower neighbour in ANOTHER tile (finished in an earlier launch: smaller T0+T1+T2) is not
             // in this wave's registers.  Its D~^-1 comes from that tile's backward chunk, its A_mc from the re-ordered
             // Jacobian.  Lower neighbour tiles are never partial along the axis they are crossed in.
@@ -277,9 +281,12 @@ __global__ __launch_bounds__(64) void k_ilu_factor(IluGeom G, const double *__re
                 }
             }
         }
-        double *fch = fwd + chunk_idx(G, tile, s) * (MW ? (long)2 * B * PFR * G.nl : (long)L::PF * RS);
-        double *bch = bwd + chunk_idx(G, tile, s) * (MW ? (long)2 * B * PBR * G.nl : (long)L::PB * RS);
+        // (multi-wave layout: lanes beyond the tile's columns store into the dump chunk behind the last real one -- ilu_setup
+        // allocates it with 128 doubles of slack -- instead of not storing)
         const bool mlive = lane < G.nl;
+        const long chs = MW ? (mlive ? chunk_idx(G, tile, s) : (long)G.ntiles * G.nsteps) : chunk_idx(G, tile, s);
+        double *fch = fwd + chs * (MW ? (long)2 * B * PFR * G.nl : (long)L::PF * RS);
+        double *bch = bwd + chs * (MW ? (long)2 * B * PBR * G.nl : (long)L::PB * RS);
         auto fidx = [&](int a, int r, int q) { return MW ? ((long)(r * PFR + ((a * B + q) >> 1)) * G.nl + lane) * 2 + ((a * B + q) & 1)
                                                          : (long)((((a * B + r) * B + q) >> 1) * RS + lane * 2 + (((a * B + r) * B + q) & 1)); };
         auto bidx = [&](int a, int r, int q) { return MW ? ((long)(r * PBR + ((a * B + q) >> 1)) * G.nl + lane) * 2 + ((a * B + q) & 1)
@@ -308,7 +315,7 @@ __global__ __launch_bounds__(64) void k_ilu_factor(IluGeom G, const double *__re
 #pragma unroll
                     for (int t = 0; t < B; ++t) v += Bm[r][t] * Amc[a][t][q];
                     D[r][q] -= v;
-                    if (MW ? mlive : live) fch[fidx(a, r, q)] = Bm[r][q];
+                    if (MW || live) fch[fidx(a, r, q)] = Bm[r][q];
                 }
         }
         if (!MW && (L::NEF & 1) && live) fch[(L::NEF >> 1) * RS + lane * 2 + 1] = 0.0;    // padding half of the last pair
@@ -330,13 +337,13 @@ __global__ __launch_bounds__(64) void k_ilu_factor(IluGeom G, const double *__re
                     double v = 0.0;
 #pragma unroll
                     for (int t = 0; t < B; ++t) v += Di[r][t] * k.Aup[a][t][q];
-                    if (MW ? mlive : live) bch[bidx(a, r, q)] = v;
+                    if (MW || live) bch[bidx(a, r, q)] = v;
                 }
 #pragma unroll
         for (int r = 0; r < B; ++r)
 #pragma unroll
             for (int q = 0; q < B; ++q) {
-                if (MW ? mlive : live) bch[bidx(3, r, q)] = Di[r][q];
+                if (MW || live) bch[bidx(3, r, q)] = Di[r][q];
                 Dp[r][q] = Di[r][q];
             }
 #pragma unroll
@@ -347,14 +354,14 @@ __global__ __launch_bounds__(64) void k_ilu_factor(IluGeom G, const double *__re
                 for (int q = 0; q < B; ++q) Aprev[a][r][q] = k.Aup[a][r][q];
     };
     load(buf[0], 0);
-    for (int s = 0; s < ns; s += 2) {
-        if (s + 1 < ns) load(buf[1], s + 1);
+    int s = 0;
+    for (; s + 2 <= ns; s += 2) {
+        load(buf[1], min(s + 1, ns - 1));
         step(buf[0], s);
-        if (s + 1 < ns) {
-            if (s + 2 < ns) load(buf[0], s + 2);
-            step(buf[1], s + 1);
-        }
+        load(buf[0], min(s + 2, ns - 1));
+        step(buf[1], s + 1);
     }
+    if (s < ns) step(buf[0], s);
 }
 
 // one chunk = NP double2 per live lane, coalesced (rows of nl double2)
@@ -1473,8 +1480,9 @@ static void alloc_factor(IluData &d, bool compact) {
     using L = IluLayout<B>;
     const size_t chunks = (size_t)d.ntiles * d.nsteps,
                  rs = compact ? (size_t)2 * ((d.t1 * d.t2 + ILU_ROW_ALIGN - 1) / ILU_ROW_ALIGN * ILU_ROW_ALIGN) : 128;
-    d.fwd.alloc(chunks * std::max((size_t)L::PF * rs, (size_t)B * ((3 * B + 1) / 2) * 2 * d.t1 * d.t2));   // (multi-wave layout: padded rows)
-    d.bwd.alloc(chunks * L::PB * rs);
+    // (+ one dump chunk and 128 doubles of slack: where k_ilu_factor's column-less lanes store in the multi-wave layout)
+    d.fwd.alloc((chunks + 1) * std::max((size_t)L::PF * rs, (size_t)B * ((3 * B + 1) / 2) * 2 * d.t1 * d.t2) + 128);   // (multi-wave layout: padded rows)
+    d.bwd.alloc((chunks + 1) * L::PB * rs + 128);
     d.ytmp.alloc(chunks * L::PY * rs + (size_t)d.ntiles * 64 * B);     // + parking slots of idle lanes (branch-free stores)
     d.jt.alloc(chunks * L::PJ * rs);
 }
@@ -1609,7 +1617,7 @@ void ilu_factor(tp_ctx *c) {
                            dim3(64 * ILU_SEG), 0, c->stream, G, c->J.p, c->ilu.jt.p);                                   \
         if (c->ilu.whole) {                                                                                            \
             for (int dg = 0; dg < c->ilu.ndiag; ++dg)      /* one launch per tile-diagonal: its lower neighbours are done */ \
-                hipLaunchKernelGGL((k_ilu_factor<BB, CC, true>), dim3(c->ilu.diag_off[dg + 1] - c->ilu.diag_off[dg]), dim3(64), 0, \
+                hipLaunchKernelGGL((k_ilu_factor<BB, CC, true, true>), dim3(c->ilu.diag_off[dg + 1] - c->ilu.diag_off[dg]), dim3(64), 0, \
                                    c->stream, G, c->ilu.jt.p, c->ilu.fwd.p, c->ilu.bwd.p,                              \
                                    (const int *)c->ilu.diag_tiles.p + c->ilu.diag_off[dg]);                            \
         } else if (c->ilu.mw) hipLaunchKernelGGL((k_ilu_factor<BB, CC, true>), dim3(c->ilu.ntiles), dim3(64), 0, c->stream, G, \
