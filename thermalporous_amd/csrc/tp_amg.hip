@@ -417,7 +417,7 @@ __device__ __forceinline__ double restrict_cell(const LevelDevT<R> &Lf, const Gr
 // and execute as seven dependent round trips (~5 us of a 9.6 us kernel on the 10^5-cell levels); like this they are
 // one batch.  Neighbours that do not exist are multiplied by their zero stencil coefficient (every level keeps
 // exact zeros towards physical boundaries), so no existence tests are needed -- only memory-safe indices.
-template <class R>
+template <class R, bool MASK = true>
 __device__ __forceinline__ double prolong_val(const LevelDevT<R> &Lf, const GridDev &gc, const double *__restrict__ ec,
                                               int F0, int F1, int F2) {
     const GridDev &g = Lf.g;
@@ -434,7 +434,14 @@ __device__ __forceinline__ double prolong_val(const LevelDevT<R> &Lf, const Grid
     const bool hasR = isF && (Ia + 1 < nca || open_hi(gc, a));
     const double wm = (double)Lf.wm[cf], wp = (double)Lf.wp[cf];
     const double e0 = ec[ci], e1 = ec[hasR ? ci + cs : ci];
-    return isF ? wm * e0 + (hasR ? wp * e1 : 0.0) : e0;
+    // 0/1 FACTORS, not selects: `isF ? expr : e0` lets the compiler sink the weight loads into a branch on isF, and the seven
+    // calls of a stencil then execute as seven dependent load batches (29 branches and 42 vmcnt waits in k_amg_prolong2_jacobi's
+    // ISA: 8.3 us for 4096 cells).  A product with a loaded value cannot be skipped; 1.0 * x and x + 0.0 * y are exact.
+    // (MASK = false: the select form, for the bandwidth-bound top levels, where the loads a C point can skip are traffic:
+    // k_amg_prolong_add 7.6 -> 9.5 us on C4's level 0 with factors, k_amg_prolong2_jacobi 8.3 -> 5.9 us on the small levels)
+    if constexpr (!MASK) return isF ? wm * e0 + (hasR ? wp * e1 : 0.0) : e0;
+    const double fF = isF ? 1.0 : 0.0, fR = hasR ? 1.0 : 0.0;
+    return (1.0 - fF) * e0 + fF * (wm * e0 + fR * (wp * e1));
 }
 
 template <class R>
@@ -524,7 +531,8 @@ __device__ __forceinline__ double prolong2_val(const LevelDevT<R> &L0, const Lev
     const long cf = g.np + (long)F0 + (long)g.n0 * F1 + g.np * F2;
     const double wm = (double)L0.wm[cf], wp = (double)L0.wp[cf];
     const double v0 = prolong_val(L1, g2, e2, I0, I1, I2), v1 = prolong_val(L1, g2, e2, J0, J1, J2);
-    return isF ? wm * v0 + (hasR ? wp * v1 : 0.0) : v0;
+    const double fF = isF ? 1.0 : 0.0, fR = hasR ? 1.0 : 0.0;          // (factors, not selects: see prolong_val)
+    return (1.0 - fF) * v0 + fF * (wm * v0 + fR * (wp * v1));
 }
 // x' = P_l P_{l+1} e2 ;  out = x' + invd (b - A x')     (level l has no pre-smoothing)
 template <class R>
@@ -619,7 +627,7 @@ __global__ __launch_bounds__(256) void k_amg_prolong_set(LevelDevT<R> Lf, GridDe
     if (tid >= Lf.g.nown) return;
     int i0, i1, i2;
     cell_ijk(Lf.g, tid, i0, i1, i2);
-    out[Lf.g.np + tid] = prolong_val(Lf, gc, ec, i0, i1, i2);
+    out[Lf.g.np + tid] = prolong_val<R, false>(Lf, gc, ec, i0, i1, i2);
 }
 template <class R>
 __global__ __launch_bounds__(256) void k_amg_prolong_add(LevelDevT<R> Lf, GridDev gc, const double *__restrict__ ec,
@@ -628,7 +636,7 @@ __global__ __launch_bounds__(256) void k_amg_prolong_add(LevelDevT<R> Lf, GridDe
     if (tid >= Lf.g.nown) return;
     int i0, i1, i2;
     cell_ijk(Lf.g, tid, i0, i1, i2);
-    x[Lf.g.np + tid] += prolong_val(Lf, gc, ec, i0, i1, i2);
+    x[Lf.g.np + tid] += prolong_val<R, false>(Lf, gc, ec, i0, i1, i2);
 }
 
 // ---- the tail: all small levels in one workgroup --------------------------------------------------------
