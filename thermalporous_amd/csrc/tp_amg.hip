@@ -647,7 +647,8 @@ __global__ __launch_bounds__(1024) void k_amg_tail(const LevelDevT<R> *lv, int l
     // trunc >= l0: the hierarchy ends at level `trunc` with two damped-Jacobi sweeps instead of the dense solve
     const int nlev = trunc >= 0 ? trunc + 1 : nlev_all;
     extern __shared__ double dyn[];          // 4 x lds_doubles: the b, e, x, x2 vectors of every tail level
-    const int T = blockDim.x, t = threadIdx.x;
+    constexpr int T = 1024;            // (the launch's block size, as a constant: no blockDim fetch -- tp_common.hpp:xcd_tid)
+    const int t = threadIdx.x;
     // level descriptors live in LDS: every phase below starts with LDS reads, not a global round trip
     static_assert(sizeof(LevelDevT<R>) % sizeof(long) == 0, "LevelDev must be a whole number of words");
     __shared__ long slv_raw[40 * sizeof(LevelDevT<R>) / sizeof(long)];

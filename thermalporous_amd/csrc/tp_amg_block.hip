@@ -574,7 +574,8 @@ struct BTailLevel {
 template <int NB>
 __global__ __launch_bounds__(512) void k_bamg_tail(const BTailLevel<NB> *__restrict__ lvg, int l0, int nlev, int ncell, const double *Minv,
                                                     const double *b_top, double *e_top) {
-    const int T = blockDim.x, t = threadIdx.x;
+    constexpr int T = 512;             // (the launch's block size, as a constant: tp_common.hpp:xcd_tid)
+    const int t = threadIdx.x;
     // level descriptors are read with scalar loads (uniform addresses): they live in SGPRs, not in the lanes' registers
     const BTailLevel<NB> *__restrict__ lv = lvg;
     // pull the read-only arrays of the tail into the L2 at once (tp_amg.hip:k_amg_tail)

@@ -58,10 +58,15 @@ inline GridDev make_grid(int n0, int n1, int n2, int gn2, int off2) {
 // hit in that XCD's L2 instead of being fetched once per XCD.  Pure performance: any placement is correct.
 // Grids launched with xcd_grid() have a multiple of 8 blocks; the kernel bounds-checks the cell index.
 #if defined(__HIPCC__)
+// Every kernel that calls this is launched with TP_BLOCK (= 256) threads (xcd_grid's default): the block size is a compile-time
+// constant here on purpose.  `blockDim.x` is a 16-bit field of the hidden kernel arguments that the compiler fetches with a
+// VECTOR load (global_load_ushort) followed by s_waitcnt vmcnt(0) before the first useful instruction: one dependent memory round
+// trip at the start of every kernel, ~0.5-1 us of the 4-6 us the small AMG levels' kernels take.
+constexpr int TP_BLOCK = 256;
 __device__ __forceinline__ long xcd_tid() {
     const unsigned nb = gridDim.x, b = blockIdx.x;
     const unsigned rb = (b & 7u) * (nb >> 3) + (b >> 3);
-    return (long)rb * blockDim.x + threadIdx.x;
+    return (long)rb * TP_BLOCK + threadIdx.x;
 }
 #endif
 inline dim3 xcd_grid(long n, int bs = 256) {

@@ -11,17 +11,17 @@ static inline dim3 grid_for(long n, int bs = 256) { return dim3((unsigned)((n + 
 
 // ---- elementwise ---------------------------------------------------------------------------------
 __global__ void k_zero(double *x, long n) {
-    const long i = (long)blockIdx.x * blockDim.x + threadIdx.x;
+    const long i = (long)blockIdx.x * TP_BLOCK + threadIdx.x;
     if (i < n) x[i] = 0.0;
 }
 __global__ void k_copy(const double *x, double *y, long n) {
-    const long i = (long)blockIdx.x * blockDim.x + threadIdx.x;
+    const long i = (long)blockIdx.x * TP_BLOCK + threadIdx.x;
     if (i < n) y[i] = x[i];
 }
 // y[f][c] (+)= a*x[f][c] over owned cells of nf fields
 template <bool ACC>
 __global__ void k_axpy_owned(GridDev g, int nf, double a, const double *x, double *y) {
-    const long t = (long)blockIdx.x * blockDim.x + threadIdx.x;
+    const long t = (long)blockIdx.x * TP_BLOCK + threadIdx.x;
     if (t >= g.nown * nf) return;
     const long f = t / g.nown, i = t - f * g.nown;
     const long c = f * g.ntot + g.np + i;
@@ -40,7 +40,7 @@ void vec_axpy_owned(tp_ctx *c, int nf, double a, const double *x, double *y) {
 // x[f][c] *= 1 / sqrt(*n2) over owned cells: v_{j+1} = w / ||w|| with the norm still on the device (the same IEEE operations
 // as the host's 1.0 / sqrt(n2) followed by vec_scale_to: bit-identical)
 __global__ void k_scale_dev_norm(GridDev g, int nf, const double *__restrict__ n2, double *x) {
-    const long t = (long)blockIdx.x * blockDim.x + threadIdx.x;
+    const long t = (long)blockIdx.x * TP_BLOCK + threadIdx.x;
     if (t >= g.nown * nf) return;
     const double a = 1.0 / sqrt(*n2);
     const long f = t / g.nown, i = t - f * g.nown;
@@ -79,7 +79,7 @@ __global__ __launch_bounds__(256) void k_multi_dot(GridDev g, int nf, const doub
                                                    const double *__restrict__ w, const double *__restrict__ w2,
                                                    double *__restrict__ partial, long nwaves) {
     constexpr int MD_CHUNK = CH;
-    const long wave = ((long)blockIdx.x * blockDim.x + threadIdx.x) >> 6;
+    const long wave = ((long)blockIdx.x * TP_BLOCK + threadIdx.x) >> 6;
     const int lane = threadIdx.x & 63;
     if (wave >= nwaves) return;
     const long nall = g.nown * nf;
@@ -238,7 +238,7 @@ double norm2(tp_ctx *c, int nf, const double *x) {
 // w += sign * sum_i h_i V_i  (VecMAXPY): one pass over w, k coalesced streams
 __global__ __launch_bounds__(256) void k_multi_axpy(GridDev g, int nf, const double *__restrict__ V, long vstride, int k,
                                                     const double *__restrict__ h, double sign, double *w) {
-    const long t = (long)blockIdx.x * blockDim.x + threadIdx.x;
+    const long t = (long)blockIdx.x * TP_BLOCK + threadIdx.x;
     if (t >= g.nown * nf) return;
     const long f = t / g.nown, i = t - f * g.nown;
     const long c = f * g.ntot + g.np + i;
@@ -275,7 +275,7 @@ __global__ __launch_bounds__(256) void k_multi_axpy_norm(GridDev g, int nf, cons
                                                          int k, const double *__restrict__ h, double *w,
                                                          double *__restrict__ partial, long nwaves, int rev) {
     constexpr int MD_CHUNK = CH;
-    const long wave_d = ((long)blockIdx.x * blockDim.x + threadIdx.x) >> 6;
+    const long wave_d = ((long)blockIdx.x * TP_BLOCK + threadIdx.x) >> 6;
     const int lane = threadIdx.x & 63;
     if (wave_d >= nwaves) return;
     // REVERSE traversal (TP_GS_REVERSE): this pass re-reads the k basis vectors the dot pass has just streamed front to back;
@@ -764,14 +764,14 @@ void decouple(tp_ctx *c) {
 
 // out = x_q - d_q x_s   (preconditioners.py:894-895, 1559-1560)
 __global__ void k_stage1_rhs(GridDev g, const double *x, const double *d, int q, int s, double *out) {
-    const long tid = (long)blockIdx.x * blockDim.x + threadIdx.x;
+    const long tid = (long)blockIdx.x * TP_BLOCK + threadIdx.x;
     if (tid >= g.nown) return;
     const long c = g.np + tid, nt = g.ntot;
     out[c] = d ? x[(long)q * nt + c] - d[(long)q * nt + c] * x[(long)s * nt + c] : x[(long)q * nt + c];
 }
 // _temp variants: out = x_p - d_T x_T - d_S x_S
 __global__ void k_stage1_rhs_temp(GridDev g, const double *x, const double *d, double *out) {
-    const long tid = (long)blockIdx.x * blockDim.x + threadIdx.x;
+    const long tid = (long)blockIdx.x * TP_BLOCK + threadIdx.x;
     if (tid >= g.nown) return;
     const long c = g.np + tid, nt = g.ntot;
     out[c] = x[c] - d[c] * x[nt + c] - d[nt + c] * x[2 * nt + c];
